@@ -1,0 +1,256 @@
+/*
+ * raytrace_amd.h — C ABI of the MI355X (gfx950) sphere path tracer.
+ *
+ * Everything the reference project (not-bottle/raytrace) does per pixel in its
+ * fragment shader shaders/testFragment.fs runs behind these entry points as
+ * hand-written HIP kernels.  Scenes are still described through the
+ * reference's scene headers: their add() methods write 32-byte std140 records
+ * through two OpenGL function pointers, and this library supplies the two
+ * functions those pointers are pointed at (rt_gl_*), then consumes the captured
+ * bytes in rt_scene_upload.
+ *
+ * Plain C, plain pointers and sizes.  All functions return 0 on success and a
+ * negative rt_status on failure; rt_last_error() gives the message of the last
+ * failure on the calling thread.  No exception crosses this boundary.
+ * A context is single-caller: calls on one rt_ctx must not overlap.
+ */
+#ifndef RAYTRACE_AMD_H
+#define RAYTRACE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_API __attribute__((visibility("default")))
+
+typedef enum rt_status {
+  RT_OK = 0,
+  RT_ERR_INVALID = -1,  /* bad argument (null, negative size, out-of-range id)  */
+  RT_ERR_DEVICE = -2,   /* a HIP call failed; message holds hipGetErrorString   */
+  RT_ERR_STATE = -3,    /* call order violated (render before upload, ...)      */
+  RT_ERR_NO_GPU = -4    /* no HIP device visible: there is no CPU fallback      */
+} rt_status;
+
+/* Material type ids.  0..3 are the reference's enum MATERIAL_TYPE
+ * (material.h:9-14).  4 is an extension of this library: a lambertian whose
+ * albedo is multiplied by perlin(k*p.x, k*p.z) of the hit point p, with
+ * perlin() the 2-D noise of the reference's perlin.h:59-85 and k = param1. */
+enum {
+  RT_MAT_NOTHING = 0,
+  RT_MAT_LAMBERTIAN = 1,
+  RT_MAT_METALLIC = 2,
+  RT_MAT_DIALECTRIC = 3,
+  RT_MAT_PERLIN_LAMBERTIAN = 4
+};
+
+/* Intersection structure chosen at rt_scene_upload. */
+enum {
+  RT_ACCEL_LINEAR = 0, /* the reference's scan over all spheres, hit_any, testFragment.fs:165-199 */
+  RT_ACCEL_LBVH = 1    /* Morton-code LBVH built on the GPU; same results as the scan            */
+};
+
+/* Random number source of rt_render. */
+enum {
+  /* xorshift32 seeded once per pixel and carried across that pixel's samples
+   * and bounces (testFragment.fs:105-110, 326-345).  Needs sample_begin == 0. */
+  RT_RNG_XORSHIFT_REF = 0,
+  /* Counter-based: the stream is a function of (seed, pixel, sample) only, so
+   * an image does not depend on how it is split into tiles or sample ranges. */
+  RT_RNG_COUNTER = 1
+};
+
+/* Byte size of one std140 sphere or material slot (sphere.h:19, material.h:22). */
+#define RT_RECORD_BYTES 32
+
+/*
+ * The render call's arguments: the fragment shader's uniform block
+ * (testFragment.fs:8-24, set at raytrace.cpp:522-533) plus what the GL draw
+ * call supplied implicitly (viewport size) and this library's partitioning
+ * (tile rectangle, sample range).  Vectors are x,y,z.
+ */
+typedef struct rt_params {
+  int32_t width, height;           /* full image size (glViewport, raytrace.cpp:511)        */
+  int32_t tile_x0, tile_y0;        /* pixels [x0,x1) x [y0,y1) are rendered by this call;   */
+  int32_t tile_x1, tile_y1;        /*   the other pixels of the accumulator are untouched   */
+  int32_t sample_begin, sample_end;/* samples [begin,end) of each pixel (num_samples = end
+                                      when begin == 0)                                      */
+  uint32_t bounce_limit;           /* uniform bounce_limit                                  */
+  uint32_t time_u32t;              /* uniform time_u32t: accepted, never read (as in the
+                                      shader, testFragment.fs:8)                            */
+  float delta_u[3];
+  float delta_v[3];
+  float camera_origin[3];
+  float viewport_top_left[3];
+  float defocus_disk_u[3];
+  float defocus_disk_v[3];
+  float defocus_angle;
+  int32_t rng_mode;                /* RT_RNG_*                                              */
+  uint32_t seed;                   /* RT_RNG_COUNTER key                                    */
+  uint32_t reserved0;
+  /* RT_RNG_XORSHIFT_REF only: width*height words, row y of the image at
+   * [y*width, (y+1)*width): the bits of (tex.r + tex.g + tex.b) that the shader
+   * reads at testFragment.fs:105-106.  Host pointer; NULL means all zero.       */
+  const uint32_t* seed_tex;
+} rt_params;
+
+/* Work counters of one instrumented render or trace (rt_get_counters). */
+typedef struct rt_counters {
+  uint64_t paths;          /* camera samples followed to termination                    */
+  uint64_t segments;       /* hit_any calls (one per ray segment)                       */
+  uint64_t sphere_tests;   /* hit_sphere calls                                          */
+  uint64_t roots;          /* quadratic roots evaluated inside hit_sphere               */
+  uint64_t node_tests;     /* LBVH box tests (0 for the linear scan)                    */
+  uint64_t hits;           /* segments that recorded a hit                              */
+  uint64_t sky;            /* segments that missed everything                           */
+  uint64_t lambertian;     /* scatter calls by kind                                     */
+  uint64_t metallic;
+  uint64_t dialectric;
+  uint64_t perlin;         /* perlin-lambertian scatters                                */
+  uint64_t unit_tries;     /* tries of the random_unit_vector rejection loop            */
+  uint64_t disk_tries;     /* tries of the random_unit_disk rejection loop              */
+  uint64_t limit_hits;     /* paths ended by the bounce limit                           */
+} rt_counters;
+
+typedef struct rt_ctx rt_ctx;
+
+/* Message of the last failure on this thread ("" if none). */
+RT_API const char* rt_last_error(void);
+
+/*
+ * Replaces: SDL/GL start-up, init() raytrace.cpp:121-184 (context creation is
+ * all that is kept of it).  Creates a context on HIP device `device`.
+ * Fails with RT_ERR_NO_GPU when no device is visible.
+ */
+RT_API int rt_init(int device, rt_ctx** out);
+
+/* Replaces: close() raytrace.cpp:214-219.  Frees device memory and the stream. */
+RT_API void rt_destroy(rt_ctx* ctx);
+
+/*
+ * Replaces: glBindBuffer, the function behind the glad pointer
+ * glad_glBindBuffer (include/glad/glad.h:1812-1814) that sphere::add
+ * (sphere.h:24-34) and material::add (material.h:30-44) call.  Remembers the
+ * buffer bound to `target`; buffer 0 unbinds.
+ */
+RT_API void rt_gl_bind_buffer(uint32_t target, uint32_t buffer);
+
+/*
+ * Replaces: glBufferSubData, behind glad_glBufferSubData
+ * (include/glad/glad.h:1827-1829).  Copies `size` bytes at `offset` into the
+ * host image of the buffer currently bound to `target`, growing it as needed.
+ * A write with nothing bound is dropped and counted (rt_gl_dropped_writes).
+ */
+RT_API void rt_gl_buffer_sub_data(uint32_t target, intptr_t offset, intptr_t size, const void* data);
+
+/*
+ * Replaces: glBufferData, behind glad_glBufferData (called at
+ * raytrace.cpp:384,419 to allocate each uniform buffer).  (Re)creates the host
+ * image of the bound buffer with `size` bytes, zero-filled when data is NULL.
+ */
+RT_API void rt_gl_buffer_data(uint32_t target, intptr_t size, const void* data, uint32_t usage);
+
+/* Captured bytes of a buffer id: pointer valid until the next capture call on
+ * this thread; *size receives the byte count (0 and NULL if never written). */
+RT_API const void* rt_gl_buffer_bytes(uint32_t buffer, size_t* size);
+/* Forget every captured buffer of this thread. */
+RT_API void rt_gl_reset(void);
+RT_API uint64_t rt_gl_dropped_writes(void);
+
+/*
+ * Replaces: the two uniform blocks "Spheres" and "Materials" the shader reads
+ * (testFragment.fs:65-73; allocated and bound at raytrace.cpp:381-391,
+ * 416-426).  Takes the std140 bytes the scene headers produced (32-byte slots:
+ * sphere = int mat @0, float radius @4, vec3 origin @16, sphere.h:22-35;
+ * material = int id @0, int type @4, float param1 @8, vec3 albedo @16,
+ * material.h:29-46), flattens them to structure-of-arrays device buffers and,
+ * for RT_ACCEL_LBVH, builds the hierarchy on the GPU.  The input is copied;
+ * the caller keeps ownership.  There is no 64-object limit.
+ * Fails with RT_ERR_INVALID if a sphere names a material slot >= n_materials.
+ */
+RT_API int rt_scene_upload(rt_ctx* ctx, const void* spheres_std140, int n_spheres,
+                           const void* materials_std140, int n_materials, int accel);
+
+/*
+ * Replaces: the draw that runs the fragment shader over the viewport,
+ * glDrawElements at raytrace.cpp:536 (and the never-called tiled variant
+ * shader_chunk_pass, raytrace.cpp:598-630, whose c_min/c_max this call's tile
+ * rectangle implements).  Adds the radiance of samples [sample_begin,
+ * sample_end) of every pixel of the tile to the context's FP32 accumulator
+ * (allocated and zeroed when the image size changes or rt_clear is called).
+ * Asynchronous on the context's stream.
+ */
+RT_API int rt_render(rt_ctx* ctx, const rt_params* p);
+
+/* Same render with the work counters switched on (slower; not for timing). */
+RT_API int rt_render_counted(rt_ctx* ctx, const rt_params* p);
+
+/* Zero the accumulator and the accumulated-sample count. */
+RT_API int rt_clear(rt_ctx* ctx);
+
+/*
+ * Use caller-owned device memory (width*height*3 floats, RGB interleaved) as
+ * the accumulator, e.g. a tensor a collective library will reduce across GPUs.
+ * NULL returns to the context-owned buffer.  The memory is not cleared here.
+ */
+RT_API int rt_set_accumulator(rt_ctx* ctx, void* device_rgb, int width, int height);
+
+/* Set how many samples per pixel the accumulator holds (after an external
+ * reduction added other GPUs' sample ranges into it). */
+RT_API int rt_set_accumulated_samples(rt_ctx* ctx, int samples);
+
+/*
+ * Replaces: the end of the shader's main (colour / num_samples and the
+ * 1/2.2 gamma, testFragment.fs:135-140) and the RGB8 colour attachment the
+ * result lands in (raytrace.cpp:574).  Waits for the stream.  rgb_linear
+ * (nullable) receives width*height*3 floats, the mean radiance before gamma;
+ * rgb8 (nullable) receives width*height*3 bytes, gamma-encoded, clamped to
+ * [0,1] and rounded to nearest.  Row 0 is the top row (origin_upper_left,
+ * testFragment.fs:3).  Host pointers.
+ */
+RT_API int rt_readback(rt_ctx* ctx, float* rgb_linear, uint8_t* rgb8);
+
+/*
+ * Replaces: hit_any, testFragment.fs:165-199, called on a batch of rays
+ * instead of from inside a path.  o_xyz, d_xyz: n rays, 3 floats each
+ * (direction need not be normalised).  id: index of the closest sphere in
+ * upload order, or -1; t: ray parameter of the hit (-1 on a miss); nrm: the
+ * hit record's normal, 3 floats (flipped against the ray as at :190-193;
+ * 0,0,0 on a miss).  Host pointers; copies in and out.  Uses the accel chosen
+ * at upload; both give the same answers.
+ */
+RT_API int rt_trace_batch(rt_ctx* ctx, const float* o_xyz, const float* d_xyz, size_t n,
+                          int32_t* id, float* t, float* nrm);
+
+/* Same, on device pointers already resident in HBM; asynchronous on the
+ * context's stream.  `counted` != 0 switches the work counters on. */
+RT_API int rt_trace_batch_device(rt_ctx* ctx, const float* o_xyz, const float* d_xyz, size_t n,
+                                 int32_t* id, float* t, float* nrm, int counted);
+
+/* Wait for everything queued on the context's stream. */
+RT_API int rt_synchronize(rt_ctx* ctx);
+
+/* Counters of the last *_counted call (waits for the stream). */
+RT_API int rt_get_counters(rt_ctx* ctx, rt_counters* out);
+
+/* Device time in milliseconds of the last render or trace kernel, measured
+ * with HIP events recorded on the context's stream around the launch (waits
+ * for the stream).  *kernel_name (nullable) receives a static string. */
+RT_API int rt_last_kernel_ms(rt_ctx* ctx, float* ms, const char** kernel_name);
+
+/* Device time of the last LBVH build (all of its kernels), in milliseconds. */
+RT_API int rt_last_build_ms(rt_ctx* ctx, float* ms);
+
+/* Depth of the LBVH of the uploaded scene (largest number of ancestors of a
+ * leaf; it sizes the traversal stack).  0 for the linear scan. */
+RT_API int rt_lbvh_depth(rt_ctx* ctx);
+
+/* Number of HIP devices visible (0 if none or the runtime cannot start). */
+RT_API int rt_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYTRACE_AMD_H */

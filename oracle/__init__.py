@@ -1,0 +1,116 @@
+"""Python face of the CPU checker (oracle/rt_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by
+bench.py's cpu_baseline leg.  The shipped package (raytrace_amd/) never imports
+this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from raytrace_amd._lib import RtCounters, RtParams
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "librt_oracle.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            subprocess.check_call(["make", "-C", HERE])
+        L = ctypes.CDLL(LIB)
+        P = ctypes.POINTER
+        L.orc_render.restype = ctypes.c_int
+        L.orc_render.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, P(RtParams),
+                                 ctypes.c_void_p, P(RtCounters), ctypes.c_int]
+        L.orc_resolve.restype = None
+        L.orc_resolve.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_trace_batch.restype = ctypes.c_int
+        L.orc_trace_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, P(RtCounters), ctypes.c_int]
+        L.orc_xorshift32.restype = ctypes.c_uint32
+        L.orc_xorshift32.argtypes = [P(ctypes.c_uint32)]
+        L.orc_rand_float.restype = ctypes.c_float
+        L.orc_rand_float.argtypes = [P(ctypes.c_uint32), ctypes.c_int]
+        L.orc_cantor.restype = ctypes.c_uint32
+        L.orc_cantor.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+        L.orc_counter_key.restype = ctypes.c_uint32
+        L.orc_counter_key.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+        f3 = P(ctypes.c_float)
+        L.orc_hit_sphere.restype = ctypes.c_float
+        L.orc_hit_sphere.argtypes = [f3, ctypes.c_float, f3, f3]
+        L.orc_shlick.restype = ctypes.c_float
+        L.orc_shlick.argtypes = [ctypes.c_float, ctypes.c_float]
+        L.orc_shade_sky.restype = None
+        L.orc_shade_sky.argtypes = [f3, f3, f3]
+        L.orc_random_unit_vector.restype = None
+        L.orc_random_unit_vector.argtypes = [P(ctypes.c_uint32), ctypes.c_int, f3, P(ctypes.c_int)]
+        L.orc_random_unit_disk.restype = None
+        L.orc_random_unit_disk.argtypes = [P(ctypes.c_uint32), ctypes.c_int, f3, P(ctypes.c_int)]
+        L.orc_reflect.restype = None
+        L.orc_reflect.argtypes = [f3, f3, f3]
+        L.orc_refract.restype = None
+        L.orc_refract.argtypes = [f3, f3, ctypes.c_float, f3]
+        L.orc_perlin.restype = ctypes.c_float
+        L.orc_perlin.argtypes = [ctypes.c_float, ctypes.c_float]
+        L.orc_perlin_gradient.restype = None
+        L.orc_perlin_gradient.argtypes = [ctypes.c_int, ctypes.c_int, f3]
+        _lib = L
+    return _lib
+
+
+def _vec(v):
+    return (ctypes.c_float * 3)(*[float(x) for x in v])
+
+
+def render(scene, params, threads=1, seed_tex=None):
+    """Radiance SUM over the params' sample range -> (accum float32 [H,W,3], counters dict)."""
+    p = params.copy()
+    if seed_tex is not None:
+        seed_tex = np.ascontiguousarray(seed_tex, dtype=np.uint32)
+        p.seed_tex = seed_tex.ctypes.data
+    accum = np.zeros((p.height, p.width, 3), dtype=np.float32)
+    c = RtCounters()
+    rc = lib().orc_render(scene.spheres, scene.n_spheres, scene.materials, scene.n_materials, ctypes.byref(p),
+                          accum.ctypes.data, ctypes.byref(c), int(threads))
+    if rc:
+        raise RuntimeError(f"orc_render failed ({rc})")
+    return accum, c.as_dict()
+
+
+def resolve(accum, samples):
+    """Mean + gamma + RGB8 of the end of the shader's main -> (linear float32, rgb8 uint8)."""
+    accum = np.ascontiguousarray(accum, dtype=np.float32)
+    lin = np.empty_like(accum)
+    q = np.empty(accum.shape, dtype=np.uint8)
+    lib().orc_resolve(accum.ctypes.data, accum.size // 3, int(samples), lin.ctypes.data, q.ctypes.data)
+    return lin, q
+
+
+def trace(scene, origins, directions, threads=1):
+    o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+    n = o.shape[0]
+    ids = np.empty(n, dtype=np.int32)
+    t = np.empty(n, dtype=np.float32)
+    nrm = np.empty((n, 3), dtype=np.float32)
+    c = RtCounters()
+    rc = lib().orc_trace_batch(scene.spheres, scene.n_spheres, o.ctypes.data, d.ctypes.data, n, ids.ctypes.data,
+                               t.ctypes.data, nrm.ctypes.data, ctypes.byref(c), int(threads))
+    if rc:
+        raise RuntimeError(f"orc_trace_batch failed ({rc})")
+    return ids, t, nrm, c.as_dict()
+
+
+def hit_sphere(centre, radius, direction, origin):
+    return float(lib().orc_hit_sphere(_vec(centre), float(radius), _vec(direction), _vec(origin)))
+
+
+def shade_sky(direction, albedo):
+    out = (ctypes.c_float * 3)()
+    lib().orc_shade_sky(_vec(direction), _vec(albedo), out)
+    return [float(x) for x in out]

@@ -1,0 +1,211 @@
+"""raytrace_amd — MI355X-native sphere path tracer behind the not-bottle/raytrace scene API.
+
+Python here is a thin driver over the C ABI (include/raytrace_amd.h) for tests
+and benchmarks; the product is the HIP library.  Scene construction and camera
+set-up run in the C++ host harness (raytrace_amd/host), rendering and hit tests
+in HIP kernels (raytrace_amd/csrc).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import RtCamera, RtCounters, RtParams  # noqa: F401
+
+ACCEL_LINEAR, ACCEL_LBVH = 0, 1
+RNG_XORSHIFT_REF, RNG_COUNTER = 0, 1
+SCENE_DEFAULT, SCENE_RANDOM_SPHERES, SCENE_PERLIN, SCENE_CLOUD = 0, 1, 2, 3
+MATERIAL_BUFFER, SPHERE_BUFFER = 1, 2
+RECORD_BYTES = 32
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"rt error {code}: {message}")
+        self.code = code
+
+
+class Scene:
+    """std140 bytes of a scene as the scene headers' add() calls produced them."""
+
+    def __init__(self, spheres: bytes, materials: bytes):
+        assert len(spheres) % RECORD_BYTES == 0 and len(materials) % RECORD_BYTES == 0
+        self.spheres = spheres
+        self.materials = materials
+
+    @property
+    def n_spheres(self):
+        return len(self.spheres) // RECORD_BYTES
+
+    @property
+    def n_materials(self):
+        return len(self.materials) // RECORD_BYTES
+
+
+def build_scene(scene_id, n=0, seed=0) -> Scene:
+    """Run a scene builder of the host harness (through the scene description API) and collect the captured bytes."""
+    lib = _lib.host_lib()
+    nm = ctypes.c_int(0)
+    ns = lib.rt_host_build_scene(int(scene_id), int(n), int(seed), ctypes.byref(nm))
+    if ns < 0:
+        raise RtError(ns, "rt_host_build_scene failed")
+
+    def grab(buffer_id, count):
+        size = ctypes.c_size_t(0)
+        ptr = lib.rt_gl_buffer_bytes(buffer_id, ctypes.byref(size))
+        need = count * RECORD_BYTES
+        if ptr is None or size.value < need:
+            raise RtError(-3, f"captured buffer {buffer_id} holds {size.value} bytes, need {need}")
+        return ctypes.string_at(ptr, need)
+
+    scene = Scene(grab(SPHERE_BUFFER, ns), grab(MATERIAL_BUFFER, nm.value))
+    lib.rt_gl_reset()
+    return scene
+
+
+def scene_camera(scene_id) -> RtCamera:
+    cam = RtCamera()
+    rc = _lib.host_lib().rt_host_scene_camera(int(scene_id), ctypes.byref(cam))
+    if rc:
+        raise RtError(rc, "rt_host_scene_camera failed")
+    return cam
+
+
+def make_params(cam: RtCamera, width, height, samples, bounce_limit=50, rng_mode=RNG_COUNTER, seed=0x5EED0001,
+                sample_begin=0) -> RtParams:
+    """Camera block + uniform wiring (raytrace.cpp:341-366, 522-533) for a full-image render."""
+    p = RtParams()
+    rc = _lib.host_lib().rt_host_camera(ctypes.byref(cam), int(width), int(height), ctypes.byref(p))
+    if rc:
+        raise RtError(rc, "rt_host_camera failed")
+    p.sample_begin = sample_begin
+    p.sample_end = sample_begin + samples
+    p.bounce_limit = bounce_limit
+    p.rng_mode = rng_mode
+    p.seed = seed
+    p.seed_tex = None
+    return p
+
+
+def gen_rays(seed, first, n):
+    """Synthetic hit-test batch of the host harness: (origins, directions), float32 [n,3] each."""
+    o = np.empty((n, 3), dtype=np.float32)
+    d = np.empty((n, 3), dtype=np.float32)
+    rc = _lib.host_lib().rt_host_gen_rays(int(seed), int(first), int(n), o.ctypes.data, d.ctypes.data)
+    if rc:
+        raise RtError(rc, "rt_host_gen_rays failed")
+    return o, d
+
+
+class Renderer:
+    """One rt_ctx.  Every method is a direct call of the C ABI."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.device_lib()
+        self.ctx = ctypes.c_void_p()
+        self._check(self.lib.rt_init(int(device), ctypes.byref(self.ctx)))
+        self.width = self.height = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RtError(rc, self.lib.rt_last_error().decode())
+
+    def close(self):
+        if self.ctx:
+            self.lib.rt_destroy(self.ctx)
+            self.ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, scene: Scene, accel=ACCEL_LINEAR):
+        self._check(self.lib.rt_scene_upload(self.ctx, scene.spheres, scene.n_spheres, scene.materials,
+                                             scene.n_materials, int(accel)))
+
+    def render(self, params: RtParams, counted=False, seed_tex=None):
+        p = params.copy()
+        if seed_tex is not None:
+            seed_tex = np.ascontiguousarray(seed_tex, dtype=np.uint32)
+            assert seed_tex.size == p.width * p.height
+            p.seed_tex = seed_tex.ctypes.data
+        fn = self.lib.rt_render_counted if counted else self.lib.rt_render
+        self._check(fn(self.ctx, ctypes.byref(p)))
+        self.width, self.height = p.width, p.height
+
+    def clear(self):
+        self._check(self.lib.rt_clear(self.ctx))
+
+    def set_accumulator(self, device_ptr, width, height):
+        self._check(self.lib.rt_set_accumulator(self.ctx, ctypes.c_void_p(device_ptr), int(width), int(height)))
+        self.width, self.height = width, height
+
+    def set_accumulated_samples(self, samples):
+        self._check(self.lib.rt_set_accumulated_samples(self.ctx, int(samples)))
+
+    def readback(self, linear=True, rgb8=True):
+        n = self.width * self.height * 3
+        lin = np.empty(n, dtype=np.float32) if linear else None
+        q = np.empty(n, dtype=np.uint8) if rgb8 else None
+        self._check(self.lib.rt_readback(self.ctx, lin.ctypes.data if linear else None, q.ctypes.data if rgb8 else None))
+        shape = (self.height, self.width, 3)
+        return (lin.reshape(shape) if linear else None, q.reshape(shape) if rgb8 else None)
+
+    def trace(self, origins, directions):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        assert d.shape[0] == n
+        ids = np.empty(n, dtype=np.int32)
+        t = np.empty(n, dtype=np.float32)
+        nrm = np.empty((n, 3), dtype=np.float32)
+        self._check(self.lib.rt_trace_batch(self.ctx, o.ctypes.data, d.ctypes.data, n, ids.ctypes.data, t.ctypes.data,
+                                            nrm.ctypes.data))
+        return ids, t, nrm
+
+    def trace_device(self, o_ptr, d_ptr, n, id_ptr, t_ptr, nrm_ptr, counted=False):
+        self._check(self.lib.rt_trace_batch_device(self.ctx, ctypes.c_void_p(o_ptr), ctypes.c_void_p(d_ptr), int(n),
+                                                   ctypes.c_void_p(id_ptr), ctypes.c_void_p(t_ptr),
+                                                   ctypes.c_void_p(nrm_ptr), int(bool(counted))))
+
+    def synchronize(self):
+        self._check(self.lib.rt_synchronize(self.ctx))
+
+    def counters(self):
+        c = RtCounters()
+        self._check(self.lib.rt_get_counters(self.ctx, ctypes.byref(c)))
+        return c.as_dict()
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float(0)
+        name = ctypes.c_char_p()
+        self._check(self.lib.rt_last_kernel_ms(self.ctx, ctypes.byref(ms), ctypes.byref(name)))
+        return float(ms.value), (name.value or b"").decode()
+
+    def last_build_ms(self):
+        ms = ctypes.c_float(0)
+        self._check(self.lib.rt_last_build_ms(self.ctx, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def lbvh_depth(self):
+        return int(self.lib.rt_lbvh_depth(self.ctx))
+
+
+# Algorithmic FP32 work per event (add/sub/mul/div/sqrt/min count 1 each; no
+# compares, no integer work): the flop model every roofline figure here uses.
+FLOPS = {"sphere_test": 23, "root": 3, "hit_record": 17, "primary": 36, "sky": 26, "lambertian": 23,
+         "metallic": 56, "dialectric": 60, "extra_unit_try": 12, "node_test": 22}
+
+
+def algorithmic_flops(c: dict) -> float:
+    """FP32 flops of a workload from its work counters."""
+    scatters = c["lambertian"] + c["metallic"] + c["perlin"]
+    extra_tries = max(0, c["unit_tries"] - scatters)
+    return float(
+        c["paths"] * FLOPS["primary"] + c["sphere_tests"] * FLOPS["sphere_test"] + c["roots"] * FLOPS["root"]
+        + c["hits"] * FLOPS["hit_record"] + c["sky"] * FLOPS["sky"]
+        + (c["lambertian"] + c["perlin"]) * FLOPS["lambertian"] + c["metallic"] * FLOPS["metallic"]
+        + c["dialectric"] * FLOPS["dialectric"] + extra_tries * FLOPS["extra_unit_try"]
+        + c["node_tests"] * FLOPS["node_test"])

@@ -1,0 +1,76 @@
+"""Builds the native libraries in-tree (run on the CPU; hipcc cross-compiles gfx950).
+
+  raytrace_amd/libraytrace_amd.so   HIP kernels + the C ABI of include/raytrace_amd.h
+  raytrace_amd/librt_host.so        host harness of include/raytrace_amd_host.h (plain g++)
+  oracle/librt_oracle.so            the CPU checker (test infrastructure; built here, used only by tests/bench)
+  oracle/_ref/ref_harness           the reference's own headers, only where /root/reference exists
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "host")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+# -ffp-contract=off and the correctly rounded divide / sqrt are part of the
+# numerical contract: every f32 operation of the shader is one IEEE operation.
+HIP_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+    "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+    "-Wl,-rpath,/opt/rocm/lib",
+]
+CXX_FLAGS = ["-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-Wall", "-Wextra", "-fvisibility=hidden"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def _glob(d, exts):
+    return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(exts))
+
+
+def build_device(force=False, extra_flags=()):
+    out = os.path.join(HERE, "libraytrace_amd.so")
+    deps = _glob(CSRC, (".hip", ".cuh", ".cpp")) + _glob(os.path.join(ROOT, "include"), (".h",))
+    if force or _newer(out, deps):
+        _run([HIPCC] + HIP_FLAGS + list(extra_flags) + ["-o", out, os.path.join(CSRC, "rt_api.hip"), os.path.join(CSRC, "rt_gl_capture.cpp")])
+    return out
+
+
+def build_host(force=False):
+    out = os.path.join(HERE, "librt_host.so")
+    srcs = [os.path.join(HOST, "rt_host.cpp"), os.path.join(CSRC, "rt_gl_capture.cpp")]
+    deps = srcs + _glob(HOST, (".hpp",)) + _glob(os.path.join(ROOT, "include"), (".h",))
+    if force or _newer(out, deps):
+        _run(["g++"] + CXX_FLAGS + ["-o", out] + srcs)
+    return out
+
+
+def build_oracle():
+    _run(["make", "-C", os.path.join(ROOT, "oracle")])
+    if os.path.isdir("/root/reference"):
+        _run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+
+
+def build_all(force=False):
+    build_host(force)
+    build_device(force)
+    build_oracle()
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

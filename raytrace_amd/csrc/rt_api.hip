@@ -1,0 +1,604 @@
+// rt_api.hip — the C ABI of raytrace_amd.h: contexts, scene upload and
+// flattening, LBVH construction, render / trace launches, readback.
+// There is no CPU fallback anywhere in this file: without a HIP device every
+// compute entry point fails with RT_ERR_NO_GPU.
+
+#include <string.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "../../include/raytrace_amd.h"
+#include "rt_kernels.cuh"
+#include "rt_lbvh.cuh"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) return fail(RT_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+template <typename T>
+struct dev_buf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t resize(size_t count) {
+    if (count <= n && p) return hipSuccess;
+    release();
+    if (count == 0) return hipSuccess;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e == hipSuccess) n = count; else p = nullptr;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+}  // namespace
+
+struct rt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_b0 = nullptr, ev_b1 = nullptr;
+  bool have_kernel_time = false, have_build_time = false;
+  const char* last_kernel = "";
+
+  // scene (upload order)
+  bool have_scene = false;
+  int n_spheres = 0, n_materials = 0, accel = RT_ACCEL_LINEAR;
+  dev_buf<float4> sph;
+  dev_buf<float> radius, inv_r;
+  dev_buf<int32_t> sph_mat, mat_type;
+  dev_buf<float4> mat_a;
+  // LBVH
+  dev_buf<bvh_node> nodes;
+  dev_buf<float4> leaf_sph;
+  dev_buf<float> leaf_r;
+  dev_buf<int32_t> leaf_idx;
+  int root = 0, depth = 0;
+
+  // accumulator
+  dev_buf<float> accum_own;
+  float* accum_ext = nullptr;
+  int acc_w = 0, acc_h = 0;
+  int samples_lo = 0, samples_hi = 0, samples_override = -1;
+
+  dev_buf<uint32_t> seed_tex;
+  dev_buf<unsigned long long> counters;
+  dev_buf<float> out_linear;
+  dev_buf<uint8_t> out_rgb8;
+
+  float* accum() { return accum_ext ? accum_ext : accum_own.p; }
+  scene_dev view() const {
+    scene_dev s;
+    s.n_spheres = n_spheres;
+    s.n_materials = n_materials;
+    s.sph = sph.p;
+    s.inv_r = inv_r.p;
+    s.sph_mat = sph_mat.p;
+    s.mat_a = mat_a.p;
+    s.mat_type = mat_type.p;
+    s.nodes = nodes.p;
+    s.leaf_sph = leaf_sph.p;
+    s.leaf_idx = leaf_idx.p;
+    s.root = root;
+    return s;
+  }
+  bool use_bvh() const { return accel == RT_ACCEL_LBVH && n_spheres >= 1; }
+  int stack_depth() const { return depth <= 16 ? 16 : (depth <= 32 ? 32 : 64); }
+};
+
+namespace {
+
+int build_lbvh(rt_ctx* c) {
+  const int n = c->n_spheres;
+  c->depth = 0;
+  c->root = n == 1 ? ~0 : 0;
+  HIP_TRY(c->leaf_sph.resize((size_t)n));
+  HIP_TRY(c->leaf_r.resize((size_t)n));
+  HIP_TRY(c->leaf_idx.resize((size_t)n));
+  HIP_TRY(c->nodes.resize((size_t)(n > 1 ? n - 1 : 1)));
+
+  dev_buf<uint32_t> bounds, codes, codes_sorted, index, index_sorted;
+  dev_buf<int> child0, child1, node_parent, leaf_parent, max_depth;
+  dev_buf<unsigned int> arrivals;
+  dev_buf<float> node_box;
+  dev_buf<unsigned char> temp;
+  auto cleanup = [&]() {
+    bounds.release(); codes.release(); codes_sorted.release(); index.release(); index_sorted.release();
+    child0.release(); child1.release(); node_parent.release(); leaf_parent.release(); max_depth.release();
+    arrivals.release(); node_box.release(); temp.release();
+  };
+#define BUILD_TRY(expr)                                                                       \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      cleanup();                                                                              \
+      return fail(RT_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_));                     \
+    }                                                                                         \
+  } while (0)
+
+  const size_t nn = (size_t)n, ni = (size_t)(n > 1 ? n - 1 : 1);
+  BUILD_TRY(bounds.resize(6));
+  BUILD_TRY(codes.resize(nn));
+  BUILD_TRY(codes_sorted.resize(nn));
+  BUILD_TRY(index.resize(nn));
+  BUILD_TRY(index_sorted.resize(nn));
+  BUILD_TRY(child0.resize(ni));
+  BUILD_TRY(child1.resize(ni));
+  BUILD_TRY(node_parent.resize(ni));
+  BUILD_TRY(leaf_parent.resize(nn));
+  BUILD_TRY(max_depth.resize(1));
+  BUILD_TRY(arrivals.resize(ni));
+  BUILD_TRY(node_box.resize(6 * ni));
+  size_t temp_bytes = 0;
+  BUILD_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, codes.p, codes_sorted.p, index.p, index_sorted.p, nn, 0, 30,
+                                      c->stream));
+  BUILD_TRY(temp.resize(temp_bytes > 0 ? temp_bytes : 1));
+
+  hipStream_t st = c->stream;
+  const unsigned blocks_n = (unsigned)((nn + 255) / 256);
+  const unsigned blocks_i = (unsigned)((ni + 255) / 256);
+  BUILD_TRY(hipEventRecord(c->ev_b0, st));
+  BUILD_TRY(hipMemsetAsync(bounds.p, 0xFF, 3 * sizeof(uint32_t), st));
+  BUILD_TRY(hipMemsetAsync(bounds.p + 3, 0x00, 3 * sizeof(uint32_t), st));
+  BUILD_TRY(hipMemsetAsync(arrivals.p, 0, ni * sizeof(unsigned int), st));
+  BUILD_TRY(hipMemsetAsync(max_depth.p, 0, sizeof(int), st));
+  BUILD_TRY(hipMemsetAsync(leaf_parent.p, 0xFF, nn * sizeof(int), st));  // -1: a lone leaf has no parent
+  lbvh_bounds_kernel<<<blocks_n < 1024u ? blocks_n : 1024u, 256, 0, st>>>(c->sph.p, n, bounds.p);
+  lbvh_morton_kernel<<<blocks_n, 256, 0, st>>>(c->sph.p, n, bounds.p, codes.p, index.p);
+  BUILD_TRY(rocprim::radix_sort_pairs(temp.p, temp_bytes, codes.p, codes_sorted.p, index.p, index_sorted.p, nn, 0, 30, st));
+  lbvh_gather_kernel<<<blocks_n, 256, 0, st>>>(c->sph.p, c->radius.p, index_sorted.p, n, c->leaf_sph.p, c->leaf_r.p,
+                                               c->leaf_idx.p);
+  if (n > 1) {
+    lbvh_hierarchy_kernel<<<blocks_i, 256, 0, st>>>(codes_sorted.p, n, child0.p, child1.p, node_parent.p, leaf_parent.p);
+    lbvh_fit_kernel<<<blocks_n, 256, 0, st>>>(c->leaf_sph.p, c->leaf_r.p, n, child0.p, child1.p, node_parent.p,
+                                              leaf_parent.p, node_box.p, arrivals.p, max_depth.p);
+    lbvh_pack_kernel<<<blocks_i, 256, 0, st>>>(c->leaf_sph.p, c->leaf_r.p, n, child0.p, child1.p, node_box.p, c->nodes.p);
+  }
+  BUILD_TRY(hipGetLastError());
+  BUILD_TRY(hipEventRecord(c->ev_b1, st));
+  int depth = 0;
+  BUILD_TRY(hipMemcpyAsync(&depth, max_depth.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  BUILD_TRY(hipStreamSynchronize(st));
+  cleanup();
+#undef BUILD_TRY
+  c->depth = depth;
+  c->have_build_time = true;
+  if (depth > 64) return fail(RT_ERR_STATE, "LBVH depth %d exceeds the traversal stack (64)", depth);
+  return RT_OK;
+}
+
+int check_ctx(rt_ctx* c) {
+  if (!c) return fail(RT_ERR_INVALID, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  return RT_OK;
+}
+
+int check_params(rt_ctx* c, const rt_params* p) {
+  if (!p) return fail(RT_ERR_INVALID, "null params");
+  if (!c->have_scene) return fail(RT_ERR_STATE, "rt_render before rt_scene_upload");
+  if (p->width < 1 || p->height < 1 || (int64_t)p->width * p->height > (int64_t)1 << 30)
+    return fail(RT_ERR_INVALID, "bad image size %d x %d", p->width, p->height);
+  if (p->tile_x0 < 0 || p->tile_y0 < 0 || p->tile_x1 > p->width || p->tile_y1 > p->height || p->tile_x0 > p->tile_x1 ||
+      p->tile_y0 > p->tile_y1)
+    return fail(RT_ERR_INVALID, "tile [%d,%d)x[%d,%d) outside %d x %d", p->tile_x0, p->tile_x1, p->tile_y0, p->tile_y1,
+                p->width, p->height);
+  if (p->sample_begin < 0 || p->sample_end < p->sample_begin) return fail(RT_ERR_INVALID, "bad sample range");
+  if (p->rng_mode != RT_RNG_XORSHIFT_REF && p->rng_mode != RT_RNG_COUNTER) return fail(RT_ERR_INVALID, "bad rng_mode");
+  return RT_OK;
+}
+
+template <int ACCEL, int RNG, bool COUNTED>
+void launch_render_stack(int stack, dim3 grid, hipStream_t st, const render_args& a) {
+  if (ACCEL != RT_ACCEL_LBVH || stack == 16)
+    rt_render_kernel<ACCEL, RNG, COUNTED, 16><<<grid, 256, 0, st>>>(a);
+  else if (stack == 32)
+    rt_render_kernel<ACCEL, RNG, COUNTED, 32><<<grid, 256, 0, st>>>(a);
+  else
+    rt_render_kernel<ACCEL, RNG, COUNTED, 64><<<grid, 256, 0, st>>>(a);
+}
+
+template <int ACCEL, bool COUNTED>
+void launch_render_rng(int rng, int stack, dim3 grid, hipStream_t st, const render_args& a) {
+  if (rng == RT_RNG_XORSHIFT_REF)
+    launch_render_stack<ACCEL, RT_RNG_XORSHIFT_REF, COUNTED>(stack, grid, st, a);
+  else
+    launch_render_stack<ACCEL, RT_RNG_COUNTER, COUNTED>(stack, grid, st, a);
+}
+
+template <int ACCEL, bool COUNTED>
+void launch_trace_stack(int stack, unsigned blocks, hipStream_t st, const trace_args& a) {
+  if (ACCEL != RT_ACCEL_LBVH || stack == 16)
+    rt_trace_kernel<ACCEL, COUNTED, 16><<<blocks, 256, 0, st>>>(a);
+  else if (stack == 32)
+    rt_trace_kernel<ACCEL, COUNTED, 32><<<blocks, 256, 0, st>>>(a);
+  else
+    rt_trace_kernel<ACCEL, COUNTED, 64><<<blocks, 256, 0, st>>>(a);
+}
+
+int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  rc = check_params(c, p);
+  if (rc) return rc;
+  const size_t n_px = (size_t)p->width * (size_t)p->height;
+  if (c->accum_ext) {
+    if (p->width != c->acc_w || p->height != c->acc_h)
+      return fail(RT_ERR_STATE, "image %d x %d does not match the caller's accumulator %d x %d", p->width, p->height,
+                  c->acc_w, c->acc_h);
+  } else if (p->width != c->acc_w || p->height != c->acc_h || !c->accum_own.p) {
+    HIP_TRY(c->accum_own.resize(3 * n_px));
+    HIP_TRY(hipMemsetAsync(c->accum_own.p, 0, 3 * n_px * sizeof(float), c->stream));
+    c->acc_w = p->width;
+    c->acc_h = p->height;
+    c->samples_lo = c->samples_hi = 0;
+    c->samples_override = -1;
+  }
+  if (c->samples_hi == c->samples_lo) {
+    c->samples_lo = p->sample_begin;
+    c->samples_hi = p->sample_end;
+  } else {
+    if (p->sample_begin < c->samples_lo) c->samples_lo = p->sample_begin;
+    if (p->sample_end > c->samples_hi) c->samples_hi = p->sample_end;
+  }
+
+  render_args a;
+  a.p = *p;
+  a.p.seed_tex = nullptr;
+  a.sc = c->view();
+  a.accum = c->accum();
+  a.seed_tex = nullptr;
+  a.counters = nullptr;
+  if (p->rng_mode == RT_RNG_XORSHIFT_REF && p->seed_tex) {
+    HIP_TRY(c->seed_tex.resize(n_px));
+    HIP_TRY(hipMemcpyAsync(c->seed_tex.p, p->seed_tex, n_px * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    a.seed_tex = c->seed_tex.p;
+  }
+  if (counted) {
+    HIP_TRY(c->counters.resize(sizeof(rt_counters) / sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(rt_counters), c->stream));
+    a.counters = c->counters.p;
+  }
+  const int tw = p->tile_x1 - p->tile_x0, th = p->tile_y1 - p->tile_y0;
+  if (tw == 0 || th == 0 || p->sample_end == p->sample_begin) return RT_OK;
+  dim3 grid((unsigned)((tw + 15) / 16), (unsigned)((th + 15) / 16));
+  const bool bvh = c->use_bvh();
+  const int stack = c->stack_depth();
+  HIP_TRY(hipEventRecord(c->ev_k0, c->stream));
+  if (bvh) {
+    if (counted) launch_render_rng<RT_ACCEL_LBVH, true>(p->rng_mode, stack, grid, c->stream, a);
+    else launch_render_rng<RT_ACCEL_LBVH, false>(p->rng_mode, stack, grid, c->stream, a);
+    c->last_kernel = "rt_render_kernel<lbvh>";
+  } else {
+    if (counted) launch_render_rng<RT_ACCEL_LINEAR, true>(p->rng_mode, stack, grid, c->stream, a);
+    else launch_render_rng<RT_ACCEL_LINEAR, false>(p->rng_mode, stack, grid, c->stream, a);
+    c->last_kernel = "rt_render_kernel<linear>";
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev_k1, c->stream));
+  c->have_kernel_time = true;
+  return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_error.c_str(); }
+
+int rt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int rt_init(int device, rt_ctx** out) {
+  if (!out) return fail(RT_ERR_INVALID, "null out pointer");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n < 1)
+    return fail(RT_ERR_NO_GPU, "no HIP device visible (%s); this library has no CPU path",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  if (device < 0 || device >= n) return fail(RT_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+  HIP_TRY(hipSetDevice(device));
+  rt_ctx* c = new rt_ctx();
+  c->device = device;
+  hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (err == hipSuccess) err = hipEventCreate(&c->ev_k0);
+  if (err == hipSuccess) err = hipEventCreate(&c->ev_k1);
+  if (err == hipSuccess) err = hipEventCreate(&c->ev_b0);
+  if (err == hipSuccess) err = hipEventCreate(&c->ev_b1);
+  if (err != hipSuccess) {
+    rt_destroy(c);
+    return fail(RT_ERR_DEVICE, "context set-up: %s", hipGetErrorString(err));
+  }
+  *out = c;
+  return RT_OK;
+}
+
+void rt_destroy(rt_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->sph.release(); c->radius.release(); c->inv_r.release(); c->sph_mat.release(); c->mat_type.release();
+  c->mat_a.release(); c->nodes.release(); c->leaf_sph.release(); c->leaf_r.release(); c->leaf_idx.release();
+  c->accum_own.release(); c->seed_tex.release(); c->counters.release(); c->out_linear.release(); c->out_rgb8.release();
+  if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
+  if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
+  if (c->ev_b0) (void)hipEventDestroy(c->ev_b0);
+  if (c->ev_b1) (void)hipEventDestroy(c->ev_b1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int rt_scene_upload(rt_ctx* c, const void* spheres_std140, int n_spheres, const void* materials_std140, int n_materials,
+                    int accel) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (n_spheres < 0 || n_materials < 0 || (n_spheres > 0 && !spheres_std140) || (n_materials > 0 && !materials_std140))
+    return fail(RT_ERR_INVALID, "bad scene arguments");
+  if (accel != RT_ACCEL_LINEAR && accel != RT_ACCEL_LBVH) return fail(RT_ERR_INVALID, "bad accel %d", accel);
+  c->have_scene = false;
+
+  // Flatten the 32-byte slots (sphere.h:22-35, material.h:29-46) into arrays.
+  const size_t ns = (size_t)n_spheres, nm = (size_t)n_materials;
+  std::vector<float4> sph(ns);
+  std::vector<float> radius(ns), inv_r(ns);
+  std::vector<int32_t> sph_mat(ns), mat_type(nm);
+  std::vector<float4> mat_a(nm);
+  const uint8_t* sp = static_cast<const uint8_t*>(spheres_std140);
+  for (size_t i = 0; i < ns; i++) {
+    const uint8_t* r = sp + RT_RECORD_BYTES * i;
+    int32_t m;
+    float rad, o[3];
+    std::memcpy(&m, r + 0, 4);
+    std::memcpy(&rad, r + 4, 4);
+    std::memcpy(o, r + 16, 12);
+    if (m < 0 || m >= n_materials)
+      return fail(RT_ERR_INVALID, "sphere %zu names material %d, but only %d were uploaded", i, m, n_materials);
+    sph[i] = make_float4(o[0], o[1], o[2], rad * rad);
+    radius[i] = rad;
+    inv_r[i] = 1.0f / rad;
+    sph_mat[i] = m;
+  }
+  const uint8_t* mp = static_cast<const uint8_t*>(materials_std140);
+  for (size_t i = 0; i < nm; i++) {
+    const uint8_t* r = mp + RT_RECORD_BYTES * i;
+    int32_t type;
+    float param1, alb[3];
+    std::memcpy(&type, r + 4, 4);
+    std::memcpy(&param1, r + 8, 4);
+    std::memcpy(alb, r + 16, 12);
+    mat_type[i] = type;
+    mat_a[i] = make_float4(alb[0], alb[1], alb[2], param1);
+  }
+  const size_t ns1 = ns ? ns : 1, nm1 = nm ? nm : 1;
+  HIP_TRY(c->sph.resize(ns1));
+  HIP_TRY(c->radius.resize(ns1));
+  HIP_TRY(c->inv_r.resize(ns1));
+  HIP_TRY(c->sph_mat.resize(ns1));
+  HIP_TRY(c->mat_type.resize(nm1));
+  HIP_TRY(c->mat_a.resize(nm1));
+  if (ns) {
+    HIP_TRY(hipMemcpyAsync(c->sph.p, sph.data(), ns * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->radius.p, radius.data(), ns * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->inv_r.p, inv_r.data(), ns * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->sph_mat.p, sph_mat.data(), ns * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  }
+  if (nm) {
+    HIP_TRY(hipMemcpyAsync(c->mat_type.p, mat_type.data(), nm * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->mat_a.p, mat_a.data(), nm * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the host vectors go out of scope
+  c->n_spheres = n_spheres;
+  c->n_materials = n_materials;
+  c->accel = accel;
+  c->have_build_time = false;
+  if (accel == RT_ACCEL_LBVH && n_spheres >= 1) {
+    rc = build_lbvh(c);
+    if (rc) return rc;
+  }
+  c->have_scene = true;
+  return RT_OK;
+}
+
+int rt_render(rt_ctx* c, const rt_params* p) { return render_impl(c, p, false); }
+int rt_render_counted(rt_ctx* c, const rt_params* p) { return render_impl(c, p, true); }
+
+int rt_clear(rt_ctx* c) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (c->accum() && c->acc_w > 0)
+    HIP_TRY(hipMemsetAsync(c->accum(), 0, 3 * (size_t)c->acc_w * (size_t)c->acc_h * sizeof(float), c->stream));
+  c->samples_lo = c->samples_hi = 0;
+  c->samples_override = -1;
+  return RT_OK;
+}
+
+int rt_set_accumulator(rt_ctx* c, void* device_rgb, int width, int height) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (device_rgb && (width < 1 || height < 1)) return fail(RT_ERR_INVALID, "bad accumulator size");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->accum_ext = static_cast<float*>(device_rgb);
+  if (device_rgb) {
+    c->acc_w = width;
+    c->acc_h = height;
+  } else {
+    c->acc_w = c->acc_h = 0;  // the own buffer is re-created by the next render
+  }
+  c->samples_lo = c->samples_hi = 0;
+  c->samples_override = -1;
+  return RT_OK;
+}
+
+int rt_set_accumulated_samples(rt_ctx* c, int samples) {
+  if (!c) return fail(RT_ERR_INVALID, "null context");
+  if (samples < 1) return fail(RT_ERR_INVALID, "samples must be positive");
+  c->samples_override = samples;
+  return RT_OK;
+}
+
+int rt_readback(rt_ctx* c, float* rgb_linear, uint8_t* rgb8) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!c->accum() || c->acc_w < 1) return fail(RT_ERR_STATE, "nothing rendered yet");
+  const int samples = c->samples_override > 0 ? c->samples_override : c->samples_hi - c->samples_lo;
+  if (samples < 1) return fail(RT_ERR_STATE, "no samples accumulated");
+  const size_t nv = 3 * (size_t)c->acc_w * (size_t)c->acc_h;
+  if (rgb_linear) HIP_TRY(c->out_linear.resize(nv));
+  if (rgb8) HIP_TRY(c->out_rgb8.resize(nv));
+  if (rgb_linear || rgb8) {
+    rt_resolve_kernel<<<(unsigned)((nv + 255) / 256), 256, 0, c->stream>>>(
+        c->accum(), nv, 1.0f / (float)samples, rgb_linear ? c->out_linear.p : nullptr, rgb8 ? c->out_rgb8.p : nullptr);
+    HIP_TRY(hipGetLastError());
+    if (rgb_linear)
+      HIP_TRY(hipMemcpyAsync(rgb_linear, c->out_linear.p, nv * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (rgb8) HIP_TRY(hipMemcpyAsync(rgb8, c->out_rgb8.p, nv, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RT_OK;
+}
+
+int rt_trace_batch_device(rt_ctx* c, const float* o_xyz, const float* d_xyz, size_t n, int32_t* id, float* t, float* nrm,
+                          int counted) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!c->have_scene) return fail(RT_ERR_STATE, "rt_trace_batch before rt_scene_upload");
+  if (n == 0) return RT_OK;
+  if (!o_xyz || !d_xyz || !id || !t || !nrm) return fail(RT_ERR_INVALID, "null ray or result pointer");
+  if (n > ((size_t)1 << 31) * 255) return fail(RT_ERR_INVALID, "batch too large");
+  trace_args a;
+  a.sc = c->view();
+  a.o_xyz = o_xyz;
+  a.d_xyz = d_xyz;
+  a.n = n;
+  a.id = id;
+  a.t = t;
+  a.nrm = nrm;
+  a.counters = nullptr;
+  if (counted) {
+    HIP_TRY(c->counters.resize(sizeof(rt_counters) / sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(rt_counters), c->stream));
+    a.counters = c->counters.p;
+  }
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  const int stack = c->stack_depth();
+  HIP_TRY(hipEventRecord(c->ev_k0, c->stream));
+  if (c->use_bvh()) {
+    if (counted) launch_trace_stack<RT_ACCEL_LBVH, true>(stack, blocks, c->stream, a);
+    else launch_trace_stack<RT_ACCEL_LBVH, false>(stack, blocks, c->stream, a);
+    c->last_kernel = "rt_trace_kernel<lbvh>";
+  } else {
+    if (counted) launch_trace_stack<RT_ACCEL_LINEAR, true>(stack, blocks, c->stream, a);
+    else launch_trace_stack<RT_ACCEL_LINEAR, false>(stack, blocks, c->stream, a);
+    c->last_kernel = "rt_trace_kernel<linear>";
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev_k1, c->stream));
+  c->have_kernel_time = true;
+  return RT_OK;
+}
+
+int rt_trace_batch(rt_ctx* c, const float* o_xyz, const float* d_xyz, size_t n, int32_t* id, float* t, float* nrm) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (n == 0) return RT_OK;
+  if (!o_xyz || !d_xyz || !id || !t || !nrm) return fail(RT_ERR_INVALID, "null ray or result pointer");
+  dev_buf<float> d_o, d_d, d_t, d_n;
+  dev_buf<int32_t> d_id;
+  auto cleanup = [&]() { d_o.release(); d_d.release(); d_t.release(); d_n.release(); d_id.release(); };
+  hipError_t e = d_o.resize(3 * n);
+  if (e == hipSuccess) e = d_d.resize(3 * n);
+  if (e == hipSuccess) e = d_t.resize(n);
+  if (e == hipSuccess) e = d_n.resize(3 * n);
+  if (e == hipSuccess) e = d_id.resize(n);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_o.p, o_xyz, 3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_d.p, d_xyz, 3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+  if (e != hipSuccess) {
+    cleanup();
+    return fail(RT_ERR_DEVICE, "ray batch staging: %s", hipGetErrorString(e));
+  }
+  rc = rt_trace_batch_device(c, d_o.p, d_d.p, n, d_id.p, d_t.p, d_n.p, 0);
+  if (rc == RT_OK) {
+    e = hipMemcpyAsync(id, d_id.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(t, d_t.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(nrm, d_n.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "ray batch readback: %s", hipGetErrorString(e));
+  } else {
+    (void)hipStreamSynchronize(c->stream);
+  }
+  cleanup();
+  return rc;
+}
+
+int rt_synchronize(rt_ctx* c) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RT_OK;
+}
+
+int rt_get_counters(rt_ctx* c, rt_counters* out) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!out) return fail(RT_ERR_INVALID, "null out pointer");
+  if (!c->counters.p) return fail(RT_ERR_STATE, "no counted call was made");
+  HIP_TRY(hipMemcpyAsync(out, c->counters.p, sizeof(rt_counters), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RT_OK;
+}
+
+int rt_last_kernel_ms(rt_ctx* c, float* ms, const char** kernel_name) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!ms) return fail(RT_ERR_INVALID, "null out pointer");
+  if (!c->have_kernel_time) return fail(RT_ERR_STATE, "no kernel was launched");
+  HIP_TRY(hipEventSynchronize(c->ev_k1));
+  HIP_TRY(hipEventElapsedTime(ms, c->ev_k0, c->ev_k1));
+  if (kernel_name) *kernel_name = c->last_kernel;
+  return RT_OK;
+}
+
+int rt_last_build_ms(rt_ctx* c, float* ms) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!ms) return fail(RT_ERR_INVALID, "null out pointer");
+  if (!c->have_build_time) return fail(RT_ERR_STATE, "no LBVH was built");
+  HIP_TRY(hipEventSynchronize(c->ev_b1));
+  HIP_TRY(hipEventElapsedTime(ms, c->ev_b0, c->ev_b1));
+  return RT_OK;
+}
+
+/* Depth of the LBVH of the uploaded scene (largest number of ancestors of a
+ * leaf); 0 for the linear scan. */
+int rt_lbvh_depth(rt_ctx* c) { return c ? c->depth : 0; }
+
+}  // extern "C"

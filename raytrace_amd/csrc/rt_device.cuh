@@ -1,0 +1,295 @@
+// rt_device.cuh — device-side building blocks of the path tracer (gfx950).
+//
+// Arithmetic contract: this file is compiled with -ffp-contract=off and HIP's
+// correctly rounded f32 divide / sqrt, and every function below performs the
+// IEEE binary32 operations of the reference shader (shaders/testFragment.fs)
+// in the shader's order, so results are bit-identical to a scalar CPU
+// evaluation of the same formulas.  Where GLSL leaves a built-in's rounding
+// open the choice is: dot = (x*x' + y*y') + z*z' (as vec3.h:132-137),
+// vector / scalar = (1/s) * v (vec3.h:127-130), normalize = v / sqrt(dot(v,v)),
+// reflect / refract by the GLSL 3.30 formulas, pow(x,5) = ((x*x)*(x*x))*x.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/raytrace_amd.h"
+
+#define RT_DEV __device__ __forceinline__
+
+struct f3 {
+  float x, y, z;
+};
+
+RT_DEV f3 mk3(float x, float y, float z) {
+  f3 r;
+  r.x = x;
+  r.y = y;
+  r.z = z;
+  return r;
+}
+RT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+RT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+RT_DEV f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
+RT_DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+RT_DEV f3 div3(f3 a, float s) { return (1.0f / s) * a; }
+RT_DEV f3 normalize3(f3 v) { return div3(v, sqrtf(dot3(v, v))); }
+RT_DEV f3 reflect3(f3 I, f3 N) { return I - (2.0f * dot3(N, I)) * N; }
+RT_DEV f3 refract3(f3 I, f3 N, float eta) {
+  float ni = dot3(N, I);
+  float k = 1.0f - eta * eta * (1.0f - ni * ni);
+  if (k < 0.0f) return mk3(0.0f, 0.0f, 0.0f);
+  return eta * I - (eta * ni + sqrtf(k)) * N;
+}
+RT_DEV float pow5(float x) {
+  float x2 = x * x;
+  float x4 = x2 * x2;
+  return x4 * x;
+}
+
+// ---- random numbers (testFragment.fs:326-345, 394-398) ---------------------
+
+RT_DEV uint32_t mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+
+// RNG == RT_RNG_XORSHIFT_REF: xorshift32 13/17/5 on the running state.
+// RNG == RT_RNG_COUNTER: Weyl step of the state, output = finaliser of it.
+template <int RNG>
+RT_DEV uint32_t rng_next(uint32_t& a) {
+  if (RNG == RT_RNG_XORSHIFT_REF) {
+    uint32_t x = a;
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    a = x;
+    return x;
+  } else {
+    a += 0x9E3779B9u;
+    return mix32(a);
+  }
+}
+
+template <int RNG>
+RT_DEV float rng_float(uint32_t& a) {  // 23 mantissa bits -> [1,2) - 1
+  uint32_t x = rng_next<RNG>(a);
+  x = (x & 0x007FFFFFu) | 0x3F800000u;
+  return __uint_as_float(x) - 1.0f;
+}
+
+RT_DEV uint32_t cantor_pair(uint32_t k1, uint32_t k2) {
+  uint32_t x = (k1 + k2) * (k1 + k2 + 1u);
+  x = x >> 1;
+  return x + k2;
+}
+
+RT_DEV uint32_t counter_key(uint32_t seed, uint32_t pixel, uint32_t sample) {
+  uint32_t h = mix32(seed ^ mix32(pixel));
+  return mix32(h + sample * 0x9E3779B9u);
+}
+
+// Per-lane work counters, kept in registers and flushed once per lane.
+struct lane_counters {
+  uint32_t paths, segments, sphere_tests, roots, node_tests, hits, sky;
+  uint32_t lambertian, metallic, dialectric, perlin, unit_tries, disk_tries, limit_hits;
+};
+#define RT_COUNT(c, field, n) \
+  do {                        \
+    if (COUNTED) (c).field += (n); \
+  } while (0)
+
+// Rejection sampler of testFragment.fs:351-366.  The candidate lies in [0,1)^3
+// (only the positive octant is sampled) and the state is bumped by the try
+// index before every try.
+template <int RNG, bool COUNTED>
+RT_DEV f3 random_unit_vector(uint32_t& a, lane_counters& k) {
+  uint32_t i = 0u;
+  while (true) {
+    a += i;
+    float x = rng_float<RNG>(a);
+    float y = rng_float<RNG>(a);
+    float z = rng_float<RNG>(a);
+    f3 p = mk3(x, y, z);
+    float lensq = dot3(p, p);
+    RT_COUNT(k, unit_tries, 1);
+    if (0.0f < lensq && lensq <= 1.0f) return div3(p, sqrtf(lensq));
+    i += 1u;
+  }
+}
+
+// testFragment.fs:368-383: point of the unit quarter-disk, not normalised.
+template <int RNG, bool COUNTED>
+RT_DEV f3 random_unit_disk(uint32_t& a, lane_counters& k) {
+  uint32_t i = 0u;
+  while (true) {
+    a += i;
+    float x = rng_float<RNG>(a);
+    float y = rng_float<RNG>(a);
+    float lensq = (x * x + y * y) + 0.0f * 0.0f;
+    RT_COUNT(k, disk_tries, 1);
+    if (lensq <= 1.0f) return mk3(x, y, 0.0f);
+    i += 1u;
+  }
+}
+
+template <int RNG, bool COUNTED>
+RT_DEV f3 random_on_hemisphere(uint32_t& a, f3 normal, lane_counters& k) {  // fs:385-392
+  f3 u = random_unit_vector<RNG, COUNTED>(a, k);
+  if (dot3(u, normal) >= 0.0f) return u;
+  return -u;
+}
+
+RT_DEV bool near_zero3(f3 v) {  // fs:400-403
+  const float s = 1e-8f;
+  return fabsf(v.x) < s && fabsf(v.y) < s && fabsf(v.z) < s;
+}
+
+// ---- sphere intersection (testFragment.fs:143-163) --------------------------
+
+// Roots of one sphere given the loop-invariant a = dot(d,d) and the sphere's
+// precomputed r2 = r*r.  Returns the shader's hit_sphere value: the accepted
+// root, or -1.  `disc` must be >= 0 (the caller tests it).
+template <bool COUNTED>
+RT_DEV float sphere_roots(float h, float disc, float a, lane_counters& k) {
+  RT_COUNT(k, roots, 1);
+  float sq = sqrtf(disc);
+  float t = (h - sq) / a;
+  if (t < 0.001f) {
+    RT_COUNT(k, roots, 1);
+    t = (h + sq) / a;
+    if (t < 0.001f) t = -1.0f;
+  }
+  return t;
+}
+
+// h and discriminant of fs:145-150.
+RT_DEV void sphere_disc(float cx, float cy, float cz, float r2, f3 o, f3 d, float a, float& h, float& disc) {
+  float ocx = cx - o.x, ocy = cy - o.y, ocz = cz - o.z;
+  h = (d.x * ocx + d.y * ocy) + d.z * ocz;
+  float c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - r2;
+  disc = h * h - a * c;
+}
+
+// ---- 2-D gradient noise (perlin.h:11-85) -----------------------------------
+
+RT_DEV void perlin_gradient(int ix, int iy, float& gx, float& gy) {  // perlin.h:31-43
+  unsigned a = (unsigned)ix, b = (unsigned)iy;
+  a *= 3284157443u;
+  b ^= (a << 16) | (a >> 16);
+  b *= 1911520717u;
+  a ^= (b << 16) | (b >> 16);
+  a *= 2048419325u;
+  // The angle is a double product rounded to float, and cos / sin are taken
+  // in double of that float, then narrowed (perlin.h:39-41).
+  float random = (float)((double)a * (3.14159265 / 2147483648.0));
+  double s, c;
+  sincos((double)random, &s, &c);
+  gx = (float)c;
+  gy = (float)s;
+}
+
+RT_DEV float perlin_dot_grid(int ix, int iy, float x, float y) {  // perlin.h:46-56
+  float gx, gy;
+  perlin_gradient(ix, iy, gx, gy);
+  float dx = x - (float)ix;
+  float dy = y - (float)iy;
+  return dx * gx + dy * gy;
+}
+
+RT_DEV float perlin_lerp(float a0, float a1, float w) { return (a1 - a0) * w + a0; }  // perlin.h:11-16
+
+RT_DEV float perlin2(float x, float y) {  // perlin.h:59-85
+  int x0 = (int)floorf(x);
+  int x1 = x0 + 1;
+  int y0 = (int)floorf(y);
+  int y1 = y0 + 1;
+  float sx = x - (float)x0;
+  float sy = y - (float)y0;
+  float n0 = perlin_dot_grid(x0, y0, x, y);
+  float n1 = perlin_dot_grid(x1, y0, x, y);
+  float ix0 = perlin_lerp(n0, n1, sx);
+  n0 = perlin_dot_grid(x0, y1, x, y);
+  n1 = perlin_dot_grid(x1, y1, x, y);
+  float ix1 = perlin_lerp(n0, n1, sx);
+  float value = perlin_lerp(ix0, ix1, sy);
+  return (float)(((double)value * 0.5) + 0.5);
+}
+
+// ---- shading (testFragment.fs:225-324) --------------------------------------
+
+RT_DEV float schlick(float cosine, float ri) {  // fs:310-315
+  float r0 = (1.0f - ri) / (1.0f + ri);
+  r0 = r0 * r0;
+  return r0 + (1.0f - r0) * pow5(1.0f - cosine);
+}
+
+// fs:318-324 together with its call site fs:217: the caller multiplies the
+// throughput by (throughput * sky), so the radiance is albedo^2 * sky.
+RT_DEV f3 sky_radiance(f3 dir, f3 albedo) {
+  float a = 0.5f * (1.0f + normalize3(dir).y);
+  f3 sky = (1.0f - a) * mk3(1.0f, 1.0f, 1.0f) + a * mk3(0.5f, 0.7f, 1.0f);
+  return albedo * (albedo * sky);
+}
+
+// Hit record of hit_any (fs:32-39) reduced to what shading needs.
+struct hit_rec {
+  f3 point, normal;
+  bool interior;
+  int mat;
+};
+
+// material_shade, fs:225-289.  Returns whether the path continues
+// (ray.bounce); updates dir and albedo.
+template <int RNG, bool COUNTED>
+RT_DEV bool shade_hit(const hit_rec& h, int type, float param1, f3 m_albedo, f3& dir, f3& albedo, uint32_t& rng,
+                      lane_counters& k) {
+  if (type == RT_MAT_LAMBERTIAN || type == RT_MAT_PERLIN_LAMBERTIAN) {  // fs:243-252
+    f3 nd = h.normal + random_on_hemisphere<RNG, COUNTED>(rng, h.normal, k);
+    if (near_zero3(nd)) nd = h.normal;
+    dir = nd;
+    if (type == RT_MAT_LAMBERTIAN) {
+      RT_COUNT(k, lambertian, 1);
+      albedo = albedo * m_albedo;
+    } else {
+      RT_COUNT(k, perlin, 1);
+      float n = perlin2(param1 * h.point.x, param1 * h.point.z);
+      albedo = albedo * (m_albedo * n);
+    }
+    return true;
+  }
+  if (type == RT_MAT_METALLIC) {  // fs:254-265
+    RT_COUNT(k, metallic, 1);
+    f3 r = reflect3(dir, normalize3(h.normal));
+    r = normalize3(r) + (param1 * random_unit_vector<RNG, COUNTED>(rng, k));
+    dir = r;
+    albedo = albedo * m_albedo;
+    bool go = dot3(r, h.normal) > 0.0f;
+    if (!go) albedo = mk3(0.0f, 0.0f, 0.0f);
+    return go;
+  }
+  if (type == RT_MAT_DIALECTRIC) {  // fs:267-289
+    RT_COUNT(k, dialectric, 1);
+    float ri = param1;
+    if (!h.interior) ri = 1.0f / ri;
+    f3 unit_dir = normalize3(dir);
+    f3 unit_normal = normalize3(h.normal);
+    float cos_theta = dot3(-unit_dir, h.normal);
+    cos_theta = (1.0f < cos_theta) ? 1.0f : cos_theta;  // min(x, 1.0)
+    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    bool cannot_refract = ri * sin_theta > 1.0f;
+    bool refl = cannot_refract;
+    if (!refl) refl = schlick(cos_theta, ri) > rng_float<RNG>(rng);  // no draw on total internal reflection
+    dir = refl ? reflect3(unit_dir, unit_normal) : refract3(unit_dir, unit_normal, ri);
+    return true;
+  }
+  albedo = mk3(1.0f, 0.0f, 0.0f);  // fs:236: unknown type paints red and stops
+  return false;
+}

@@ -1,0 +1,223 @@
+// rt_lbvh.cuh — GPU construction of the linear bounding volume hierarchy:
+// scene bounds -> 30-bit Morton codes of the sphere centres -> radix sort ->
+// Karras-style radix tree over the sorted codes -> bottom-up box fit -> 64-byte
+// traversal nodes.  The reference has no counterpart (it scans every sphere,
+// testFragment.fs:176-184); the hierarchy is checked against that scan.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_scene_dev.cuh"
+
+// Order-preserving map float -> uint32 (for atomicMin / atomicMax on floats).
+__device__ __forceinline__ uint32_t float_key(float f) {
+  uint32_t u = __float_as_uint(f);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float key_float(uint32_t k) {
+  uint32_t u = k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+  return __uint_as_float(u);
+}
+
+// bounds[0..2] = min keys (init 0xFFFFFFFF), bounds[3..5] = max keys (init 0).
+__global__ __launch_bounds__(256) void lbvh_bounds_kernel(const float4* sph, int n, uint32_t* bounds) {
+  uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float4 s = sph[i];
+    const uint32_t kx = float_key(s.x), ky = float_key(s.y), kz = float_key(s.z);
+    mn[0] = min(mn[0], kx); mx[0] = max(mx[0], kx);
+    mn[1] = min(mn[1], ky); mx[1] = max(mx[1], ky);
+    mn[2] = min(mn[2], kz); mx[2] = max(mx[2], kz);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    for (int off = 32; off > 0; off >>= 1) {
+      mn[a] = min(mn[a], (uint32_t)__shfl_xor((int)mn[a], off, 64));
+      mx[a] = max(mx[a], (uint32_t)__shfl_xor((int)mx[a], off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(bounds + a, mn[a]);
+      atomicMax(bounds + 3 + a, mx[a]);
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {  // 10 bits -> every third bit
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+
+__global__ __launch_bounds__(256) void lbvh_morton_kernel(const float4* sph, int n, const uint32_t* bounds, uint32_t* codes,
+                                                          uint32_t* index) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 s = sph[i];
+  const float c[3] = {s.x, s.y, s.z};
+  uint32_t q[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float lo = key_float(bounds[a]), hi = key_float(bounds[3 + a]);
+    const float ext = hi - lo;
+    float u = ext > 0.0f ? (c[a] - lo) / ext : 0.0f;
+    int v = (int)(u * 1024.0f);
+    q[a] = (uint32_t)min(max(v, 0), 1023);
+  }
+  codes[i] = (expand_bits10(q[0]) << 2) | (expand_bits10(q[1]) << 1) | expand_bits10(q[2]);
+  index[i] = (uint32_t)i;
+}
+
+// Length of the common prefix of the keys at sorted positions i and j, the key
+// being (code, position) so that equal codes still differ; -1 outside [0,n).
+__device__ __forceinline__ int lbvh_delta(const uint32_t* codes, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const uint32_t ci = codes[i], cj = codes[j];
+  if (ci != cj) return __clz((int)(ci ^ cj));
+  return 32 + __clz(i ^ j);
+}
+
+// One thread per internal node i in [0, n-2]: its key range and split.
+// child refs: >= 0 internal node, < 0 leaf (~ref = sorted position).
+__global__ __launch_bounds__(256) void lbvh_hierarchy_kernel(const uint32_t* codes, int n, int* child0, int* child1,
+                                                             int* node_parent, int* leaf_parent) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n - 1) return;
+  const int dir = (lbvh_delta(codes, n, i, i + 1) - lbvh_delta(codes, n, i, i - 1)) < 0 ? -1 : 1;
+  const int dmin = lbvh_delta(codes, n, i, i - dir);
+  int lmax = 2;
+  while (lbvh_delta(codes, n, i, i + lmax * dir) > dmin) lmax *= 2;
+  int l = 0;
+  for (int t = lmax >> 1; t >= 1; t >>= 1)
+    if (lbvh_delta(codes, n, i, i + (l + t) * dir) > dmin) l += t;
+  const int j = i + l * dir;
+  const int dnode = lbvh_delta(codes, n, i, j);
+  int s = 0;
+  int t = l;
+  do {
+    t = (t + 1) >> 1;
+    if (lbvh_delta(codes, n, i, i + (s + t) * dir) > dnode) s += t;
+  } while (t > 1);
+  const int gamma = i + s * dir + min(dir, 0);
+  const int first = min(i, j), last = max(i, j);
+  const int c0 = (first == gamma) ? ~gamma : gamma;
+  const int c1 = (last == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+  child0[i] = c0;
+  child1[i] = c1;
+  if (c0 < 0) leaf_parent[~c0] = i; else node_parent[c0] = i;
+  if (c1 < 0) leaf_parent[~c1] = i; else node_parent[c1] = i;
+  if (i == 0) node_parent[0] = -1;
+}
+
+struct box3 {
+  float lo[3], hi[3];
+};
+
+__device__ __forceinline__ box3 sphere_box(const float4* leaf_sph, const float* leaf_r, int kpos) {
+  const float4 s = leaf_sph[kpos];
+  const float r = fabsf(leaf_r[kpos]);
+  box3 b;
+  b.lo[0] = s.x - r; b.lo[1] = s.y - r; b.lo[2] = s.z - r;
+  b.hi[0] = s.x + r; b.hi[1] = s.y + r; b.hi[2] = s.z + r;
+  return b;
+}
+
+// Gather the spheres into Morton order.
+__global__ __launch_bounds__(256) void lbvh_gather_kernel(const float4* sph, const float* radius, const uint32_t* sorted_index,
+                                                          int n, float4* leaf_sph, float* leaf_r, int32_t* leaf_idx) {
+  const int kpos = blockIdx.x * 256 + threadIdx.x;
+  if (kpos >= n) return;
+  const uint32_t src = sorted_index[kpos];
+  leaf_sph[kpos] = sph[src];
+  leaf_r[kpos] = radius[src];
+  leaf_idx[kpos] = (int32_t)src;
+}
+
+// One thread per leaf climbs towards the root; at each node the first arrival
+// stops and the second one — which knows both children are finished — forms
+// the node's box.  node_box: 6 floats per internal node.  max_depth receives
+// the largest number of ancestors of any leaf.
+__global__ __launch_bounds__(256) void lbvh_fit_kernel(const float4* leaf_sph, const float* leaf_r, int n, const int* child0,
+                                                       const int* child1, const int* node_parent, const int* leaf_parent,
+                                                       float* node_box, unsigned int* arrivals, int* max_depth) {
+  const int kpos = blockIdx.x * 256 + threadIdx.x;
+  if (kpos >= n) return;
+  // depth of this leaf (independent of the fitting order)
+  int depth = 0;
+  for (int p = leaf_parent[kpos]; p >= 0; p = node_parent[p]) depth++;
+  atomicMax(max_depth, depth);
+
+  int cur = leaf_parent[kpos];
+  while (cur >= 0) {
+    const unsigned int old = atomicAdd(arrivals + cur, 1u);
+    if (old == 0u) return;  // the sibling subtree is not finished yet
+    __threadfence();        // see the boxes the sibling's thread published
+    box3 b;
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+      const int c = side == 0 ? child0[cur] : child1[cur];
+      box3 cb;
+      if (c < 0) {
+        cb = sphere_box(leaf_sph, leaf_r, ~c);
+      } else {
+        const float* src = node_box + 6 * (size_t)c;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          cb.lo[a] = __hip_atomic_load(src + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          cb.hi[a] = __hip_atomic_load(src + 3 + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (side == 0) {
+        b = cb;
+      } else {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          b.lo[a] = fminf(b.lo[a], cb.lo[a]);
+          b.hi[a] = fmaxf(b.hi[a], cb.hi[a]);
+        }
+      }
+    }
+    float* dst = node_box + 6 * (size_t)cur;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      __hip_atomic_store(dst + a, b.lo[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dst + 3 + a, b.hi[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();  // publish before announcing arrival at the parent
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    cur = node_parent[cur];
+  }
+}
+
+// Traversal nodes: each internal node carries its two children's boxes.
+__global__ __launch_bounds__(256) void lbvh_pack_kernel(const float4* leaf_sph, const float* leaf_r, int n, const int* child0,
+                                                        const int* child1, const float* node_box, bvh_node* nodes) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n - 1) return;
+  bvh_node nd;
+  nd.c0 = child0[i];
+  nd.c1 = child1[i];
+  nd.pad[0] = nd.pad[1] = 0;
+#pragma unroll
+  for (int side = 0; side < 2; side++) {
+    const int c = side == 0 ? nd.c0 : nd.c1;
+    box3 cb;
+    if (c < 0) {
+      cb = sphere_box(leaf_sph, leaf_r, ~c);
+    } else {
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        cb.lo[a] = node_box[6 * (size_t)c + a];
+        cb.hi[a] = node_box[6 * (size_t)c + 3 + a];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      if (side == 0) { nd.lo0[a] = cb.lo[a]; nd.hi0[a] = cb.hi[a]; }
+      else           { nd.lo1[a] = cb.lo[a]; nd.hi1[a] = cb.hi[a]; }
+    }
+  }
+  nodes[i] = nd;
+}

@@ -1,0 +1,218 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle.
+
+Bars: hit ids bit-exact; t, normals and linear radiance bit-exact as well
+(the kernels perform the oracle's IEEE operations in the oracle's order), which
+is stricter than the 1e-5 relative tolerance the task states for t / normal;
+RGB8 within one level (device powf vs libm powf).
+"""
+import numpy as np
+import pytest
+
+import oracle
+import raytrace_amd as rt
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_same_f32(a, b, what):
+    a, b = _bits(a), _bits(b)
+    bad = np.flatnonzero(a.ravel() != b.ravel())
+    assert bad.size == 0, f"{what}: {bad.size} of {a.size} values differ, first at {bad[:5]}"
+
+
+def rays_for(scene_id, n, seed):
+    """Rays that actually meet the scene: origins on a shell, aimed at jittered targets near the spheres."""
+    rng = np.random.default_rng(seed)
+    if scene_id == rt.SCENE_CLOUD:
+        return rt.gen_rays(seed, 0, n)
+    span = 12.0 if scene_id == rt.SCENE_RANDOM_SPHERES else 2.0
+    o = rng.normal(size=(n, 3)).astype(np.float32)
+    o /= np.linalg.norm(o, axis=1, keepdims=True)
+    o *= rng.uniform(0.0, 3.0 * span, size=(n, 1)).astype(np.float32)
+    o[:, 1] = np.abs(o[:, 1]) * 0.3 + 0.05
+    target = rng.uniform(-span, span, size=(n, 3)).astype(np.float32)
+    target[:, 1] = rng.uniform(-0.2, 1.0, size=n)
+    d = (target - o) * rng.uniform(0.5, 2.0, size=(n, 1)).astype(np.float32)
+    return o.astype(np.float32), d.astype(np.float32)
+
+
+@pytest.mark.parametrize("accel", [rt.ACCEL_LINEAR, rt.ACCEL_LBVH])
+@pytest.mark.parametrize("scene_id,n_cloud", [(rt.SCENE_DEFAULT, 0), (rt.SCENE_RANDOM_SPHERES, 0), (rt.SCENE_PERLIN, 0),
+                                              (rt.SCENE_CLOUD, 3000)])
+def test_trace_batch_matches_oracle(renderer, accel, scene_id, n_cloud):
+    scene = rt.build_scene(scene_id, n=n_cloud, seed=0xC4C4C4C4)
+    n = 4096
+    o, d = rays_for(scene_id, n, 1234 + scene_id)
+    renderer.upload(scene, accel)
+    ids, t, nrm = renderer.trace(o, d)
+    oid, ot, onrm, _ = oracle.trace(scene, o, d, threads=8)
+    assert (oid >= 0).sum() > n // 20, "the batch should hit something"
+    assert np.array_equal(ids, oid), f"{(ids != oid).sum()} hit ids differ"
+    assert_same_f32(t, ot, "t")
+    assert_same_f32(nrm, onrm, "normal")
+
+
+def test_lbvh_equals_linear_on_large_cloud(renderer):
+    """Size-independent property at a size the oracle cannot reach: both intersectors agree on every ray."""
+    scene = rt.build_scene(rt.SCENE_CLOUD, n=50000, seed=7)
+    o, d = rt.gen_rays(99, 0, 200000)
+    renderer.upload(scene, rt.ACCEL_LINEAR)
+    a = renderer.trace(o, d)
+    renderer.upload(scene, rt.ACCEL_LBVH)
+    b = renderer.trace(o, d)
+    assert (a[0] >= 0).sum() > 1000
+    assert np.array_equal(a[0], b[0]), f"{(a[0] != b[0]).sum()} ids differ"
+    assert_same_f32(a[1], b[1], "t")
+    assert_same_f32(a[2], b[2], "normal")
+
+
+def _render_both(renderer, scene, params, accel, seed_tex=None):
+    renderer.upload(scene, accel)
+    renderer.clear()
+    renderer.render(params, counted=True, seed_tex=seed_tex)
+    lin, q = renderer.readback()
+    counters = renderer.counters()
+    acc, oc = oracle.render(scene, params, threads=8, seed_tex=seed_tex)
+    olin, oq = oracle.resolve(acc, params.sample_end - params.sample_begin)
+    return lin, q, counters, olin, oq, oc
+
+
+@pytest.mark.parametrize("accel", [rt.ACCEL_LINEAR, rt.ACCEL_LBVH])
+def test_default_scene_reference_rng(renderer, accel):
+    """The reference's own configuration: default scene, 320x180, 8 spp, depth 50, xorshift per pixel."""
+    scene = rt.build_scene(rt.SCENE_DEFAULT)
+    cam = rt.scene_camera(rt.SCENE_DEFAULT)
+    p = rt.make_params(cam, 320, 180, 8, rng_mode=rt.RNG_XORSHIFT_REF)
+    lin, q, c, olin, oq, oc = _render_both(renderer, scene, p, accel)
+    assert_same_f32(lin, olin, "linear radiance")
+    assert np.abs(q.astype(int) - oq.astype(int)).max() <= 1
+    for k in ("paths", "segments", "hits", "sky", "lambertian", "metallic", "dialectric", "unit_tries", "disk_tries",
+              "limit_hits"):
+        assert c[k] == oc[k], k
+    if accel == rt.ACCEL_LINEAR:
+        assert c["sphere_tests"] == oc["sphere_tests"] and c["roots"] == oc["roots"]
+
+
+@pytest.mark.parametrize("accel", [rt.ACCEL_LINEAR, rt.ACCEL_LBVH])
+@pytest.mark.parametrize("rng_mode", [rt.RNG_XORSHIFT_REF, rt.RNG_COUNTER])
+def test_default_scene_from_lookfrom(renderer, accel, rng_mode):
+    """Same scene seen from lookfrom (the reference's camera_origin = lookat starts every path inside the ground)."""
+    scene = rt.build_scene(rt.SCENE_DEFAULT)
+    cam = rt.scene_camera(rt.SCENE_DEFAULT)
+    cam.origin_is_lookat = 0
+    for i, v in enumerate((0.0, 1.0, 2.5)):
+        cam.lookfrom[i] = v
+    for i, v in enumerate((0.0, 0.0, -1.0)):
+        cam.lookat[i] = v
+    for i, v in enumerate((0.0, 1.0, 0.0)):
+        cam.vup[i] = v
+    cam.vfov = 50.0
+    cam.focus_dist = 3.4
+    p = rt.make_params(cam, 200, 120, 6, rng_mode=rng_mode)
+    seed_tex = (np.arange(200 * 120, dtype=np.uint32) * np.uint32(2654435761)) if rng_mode == rt.RNG_XORSHIFT_REF else None
+    lin, q, c, olin, oq, oc = _render_both(renderer, scene, p, accel, seed_tex=seed_tex)
+    assert olin.mean() > 0.05, "the image must not be empty"
+    assert c["dialectric"] > 0 and c["metallic"] > 0 and c["lambertian"] > 0
+    assert_same_f32(lin, olin, "linear radiance")
+    assert np.abs(q.astype(int) - oq.astype(int)).max() <= 1
+    for k in ("paths", "segments", "hits", "sky", "lambertian", "metallic", "dialectric", "unit_tries", "disk_tries"):
+        assert c[k] == oc[k], k
+
+
+@pytest.mark.parametrize("accel", [rt.ACCEL_LINEAR, rt.ACCEL_LBVH])
+def test_random_sphere_scene_small(renderer, accel):
+    """The 487-sphere scene at a size the oracle renders in seconds."""
+    scene = rt.build_scene(rt.SCENE_RANDOM_SPHERES)
+    cam = rt.scene_camera(rt.SCENE_RANDOM_SPHERES)
+    p = rt.make_params(cam, 160, 90, 4, rng_mode=rt.RNG_COUNTER)
+    lin, q, c, olin, oq, oc = _render_both(renderer, scene, p, accel)
+    assert_same_f32(lin, olin, "linear radiance")
+    assert np.abs(q.astype(int) - oq.astype(int)).max() <= 1
+    for k in ("paths", "segments", "hits", "sky", "lambertian", "metallic", "dialectric", "unit_tries", "disk_tries"):
+        assert c[k] == oc[k], k
+
+
+def test_perlin_scene_small(renderer):
+    scene = rt.build_scene(rt.SCENE_PERLIN)
+    cam = rt.scene_camera(rt.SCENE_PERLIN)
+    p = rt.make_params(cam, 128, 72, 4, rng_mode=rt.RNG_COUNTER)
+    lin, q, c, olin, oq, oc = _render_both(renderer, scene, p, rt.ACCEL_LBVH)
+    assert c["perlin"] == oc["perlin"] and c["perlin"] > 0
+    # cos/sin of the gradient angle are evaluated in double on both sides by
+    # different libraries; a last-bit difference of one gradient is allowed.
+    np.testing.assert_allclose(lin, olin, rtol=2e-6, atol=1e-7)
+
+
+def test_tiles_and_sample_ranges_compose(renderer):
+    """Counter RNG: four tiles x two sample ranges add up to the one-call image (bitwise per pixel for the tiles)."""
+    scene = rt.build_scene(rt.SCENE_RANDOM_SPHERES)
+    cam = rt.scene_camera(rt.SCENE_RANDOM_SPHERES)
+    W, H, S = 150, 85, 6   # ragged against the 16x16 workgroup tile
+    p = rt.make_params(cam, W, H, S, rng_mode=rt.RNG_COUNTER)
+    renderer.upload(scene, rt.ACCEL_LBVH)
+    renderer.clear()
+    renderer.render(p)
+    whole, _ = renderer.readback(rgb8=False)
+    # tiles only: disjoint pixels, same sample range -> bit-identical
+    renderer.clear()
+    for (x0, x1) in ((0, 70), (70, W)):
+        for (y0, y1) in ((0, 33), (33, H)):
+            q = p.copy()
+            q.tile_x0, q.tile_x1, q.tile_y0, q.tile_y1 = x0, x1, y0, y1
+            renderer.render(q)
+    tiled, _ = renderer.readback(rgb8=False)
+    assert_same_f32(tiled, whole, "tiled image")
+    # sample ranges: same pixels, partial sums added in a different order
+    renderer.clear()
+    for (s0, s1) in ((0, 2), (2, S)):
+        q = p.copy()
+        q.sample_begin, q.sample_end = s0, s1
+        renderer.render(q)
+    split, _ = renderer.readback(rgb8=False)
+    np.testing.assert_allclose(split, whole, rtol=1e-5, atol=1e-6)
+
+
+def test_edge_cases(renderer):
+    cam = rt.scene_camera(rt.SCENE_DEFAULT)
+    cam.origin_is_lookat = 0
+    p = rt.make_params(cam, 33, 17, 2, rng_mode=rt.RNG_COUNTER)
+    # empty scene: every path is sky
+    empty = rt.Scene(b"", b"")
+    for accel in (rt.ACCEL_LINEAR, rt.ACCEL_LBVH):
+        renderer.upload(empty, accel)
+        renderer.clear()
+        renderer.render(p, counted=True)
+        lin, _ = renderer.readback(rgb8=False)
+        acc, oc = oracle.render(empty, p)
+        assert_same_f32(lin, oracle.resolve(acc, 2)[0], "empty scene")
+        assert renderer.counters()["sky"] == 33 * 17 * 2
+        ids, t, nrm = renderer.trace(np.zeros((5, 3), np.float32), np.ones((5, 3), np.float32))
+        assert (ids == -1).all() and (t == -1).all() and (nrm == 0).all()
+    # one sphere: the LBVH is a single leaf
+    scene = rt.build_scene(rt.SCENE_DEFAULT)
+    one = rt.Scene(scene.spheres[32:64], scene.materials)
+    o, d = rays_for(rt.SCENE_DEFAULT, 512, 5)
+    renderer.upload(one, rt.ACCEL_LBVH)
+    a = renderer.trace(o, d)
+    b = oracle.trace(one, o, d)
+    assert np.array_equal(a[0], b[0]) and (a[0] >= 0).any()
+    assert_same_f32(a[1], b[1], "t")
+    # zero rays, zero-size tile, zero samples: no-ops
+    renderer.trace(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    q = p.copy()
+    q.tile_x1 = q.tile_x0
+    renderer.render(q)
+    # degenerate rays (zero direction) follow the scan's NaN rule: no hit
+    renderer.upload(scene, rt.ACCEL_LBVH)
+    z = renderer.trace(np.array([[0, 0, 0]], np.float32), np.array([[0, 0, 0]], np.float32))
+    assert z[0][0] == oracle.trace(scene, [[0, 0, 0]], [[0, 0, 0]])[0][0]
+    # a sphere naming a material that was not uploaded is refused
+    bad = bytearray(scene.spheres)
+    bad[0:4] = (99).to_bytes(4, "little")
+    with pytest.raises(rt.RtError):
+        renderer.upload(rt.Scene(bytes(bad), scene.materials), rt.ACCEL_LINEAR)
+    renderer.upload(scene, rt.ACCEL_LINEAR)
