@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path on MI355X.
+
+  python bench.py [--gpus N --steps K --warmup W] [--config c2|c1|c3|c4] [--accel lbvh|linear]
+
+A step is one pass of the hot path over one batch of synthetic input:
+  c2 (default)  one 1920x1080 frame of the 487-sphere scene at 256 spp, depth 50  -> Mpaths/s
+  c1            the reference's own default render (320x180, 8 spp, xorshift RNG)   -> Mpaths/s
+  c3            the Perlin-textured scene, 1920x1080 at 1024 spp                   -> Mpaths/s
+  c4            2^20 spheres, a 10^8-ray closest-hit batch (LBVH)                  -> Mrays/s
+Scene and rays are resident in HBM before the timed region starts.
+
+With N > 1 (one process per GPU, started by torch.distributed.run) every rank
+renders its own 256-sample range of the same frame into its own accumulator
+(weak scaling: N x 256 spp in total) and the accumulators are summed onto rank
+0 with an RCCL reduce inside the timed step.  c4 splits the ray batch by index
+range and needs no collective.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X: 256 CU x 2.4 GHz x 256 flop/clk/CU
+HBM_PEAK_GBS = 8000.0
+
+CONFIGS = {
+    "c1": dict(scene="default", width=320, height=180, spp=8, rng="xorshift", workload="default scene 320x180x8spp depth50 (reference's built-in render)"),
+    "c2": dict(scene="random_spheres", width=1920, height=1080, spp=256, rng="counter", workload="487-sphere scene 1920x1080x256spp depth50"),
+    "c3": dict(scene="perlin", width=1920, height=1080, spp=1024, rng="counter", workload="Perlin-textured scene 1920x1080x1024spp depth50"),
+    "c4": dict(scene="cloud", n_spheres=1 << 20, n_rays=100_000_000, workload="2^20 spheres, 1e8-ray closest-hit batch"),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--accel", default="lbvh", choices=["lbvh", "linear"])
+    ap.add_argument("--width", type=int)
+    ap.add_argument("--height", type=int)
+    ap.add_argument("--spp", type=int)
+    ap.add_argument("--rays", type=int)
+    ap.add_argument("--spheres", type=int)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    return ap.parse_args()
+
+
+def cpu_baseline_render(rt, scene, cam, cfg, threads):
+    """The CPU restatement of the reference shader, timed on a bounded sample of the same workload."""
+    import oracle
+    # Mpaths/s does not depend on spp; pick the spp that gives roughly 10-30 s of CPU work.
+    w, h = cfg["width"], cfg["height"]
+    probe = rt.make_params(cam, w, h, 1, rng_mode=rt.RNG_COUNTER if cfg["rng"] == "counter" else rt.RNG_XORSHIFT_REF)
+    probe.tile_y1 = max(1, h // 16)
+    t0 = time.perf_counter()
+    _, c = oracle.render(scene, probe, threads=threads)
+    dt = time.perf_counter() - t0
+    rate = c["paths"] / max(dt, 1e-6)  # paths/s on `threads` threads
+    spp = int(max(1, min(cfg["spp"], round(rate * 8.0 / (w * h)))))
+    p = rt.make_params(cam, w, h, spp, rng_mode=probe.rng_mode)
+    t0 = time.perf_counter()
+    _, c = oracle.render(scene, p, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": c["paths"] / dt / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
+            "sample": f"same scene and camera, {w}x{h} at {spp} spp ({c['paths']} paths, {dt:.1f} s wall), "
+                      f"CPU restatement of the reference shader (linear scan), {threads} threads"}
+
+
+def cpu_baseline_trace(rt, scene, threads, seed):
+    import oracle
+    n = 64
+    o, d = rt.gen_rays(seed, 0, n)
+    t0 = time.perf_counter()
+    oracle.trace(scene, o, d, threads=threads)
+    dt = time.perf_counter() - t0
+    n2 = int(max(n, min(20000, n * 10.0 / max(dt, 1e-6))))
+    o, d = rt.gen_rays(seed, 0, n2)
+    t0 = time.perf_counter()
+    oracle.trace(scene, o, d, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": n2 / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"first {n2} rays of the batch against all {scene.n_spheres} spheres ({dt:.1f} s wall), "
+                      f"CPU restatement of hit_any (linear scan), {threads} threads"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch  # device memory, streams and torch.distributed only
+    import torch.distributed as dist
+    import raytrace_amd as rt
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = dict(CONFIGS[args.config])
+    for k in ("width", "height", "spp"):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
+    accel = rt.ACCEL_LBVH if args.accel == "lbvh" else rt.ACCEL_LINEAR
+    r = rt.Renderer(local_rank)
+    scene_ids = {"default": rt.SCENE_DEFAULT, "random_spheres": rt.SCENE_RANDOM_SPHERES, "perlin": rt.SCENE_PERLIN,
+                 "cloud": rt.SCENE_CLOUD}
+    sid = scene_ids[cfg["scene"]]
+    result = {}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.config == "c4":
+        n_sph = args.spheres or cfg["n_spheres"]
+        n_rays_total = args.rays or cfg["n_rays"]
+        scene = rt.build_scene(sid, n=n_sph, seed=0xC4C4C4C4)
+        r.upload(scene, accel)
+        per = (n_rays_total + world - 1) // world
+        first = rank * per
+        n = max(0, min(per, n_rays_total - first))
+        o_h, d_h = rt.gen_rays(0xC4C4C4C4, first, n)
+        o = torch.from_numpy(o_h).to(dev)
+        d = torch.from_numpy(d_h).to(dev)
+        del o_h, d_h
+        ids = torch.empty(n, dtype=torch.int32, device=dev)
+        t = torch.empty(n, dtype=torch.float32, device=dev)
+        nrm = torch.empty((n, 3), dtype=torch.float32, device=dev)
+
+        def step(counted=False):
+            r.trace_device(o.data_ptr(), d.data_ptr(), n, ids.data_ptr(), t.data_ptr(), nrm.data_ptr(), counted)
+
+        step(counted=True)
+        counters = r.counters()
+        units_per_step = n_rays_total
+        unit, metric = "Mrays/s", "closest-hit rays per second (Mrays/s)"
+        algo_bytes = 44.0 * n  # 24 B in + 20 B out per ray
+        result["config"] = {"workload": cfg["workload"] if not (args.spheres or args.rays) else f"{n_sph} spheres, {n_rays_total}-ray closest-hit batch",
+                            "accel": args.accel, "spheres": n_sph, "rays": n_rays_total, "lbvh_depth": r.lbvh_depth(),
+                            "parallelism": f"ray index ranges x{world}"}
+        if accel == rt.ACCEL_LBVH:
+            result["lbvh_build_ms"] = r.last_build_ms()
+    else:
+        scene = rt.build_scene(sid)
+        cam = rt.scene_camera(sid)
+        rng_mode = rt.RNG_COUNTER if cfg["rng"] == "counter" else rt.RNG_XORSHIFT_REF
+        if world > 1 and rng_mode != rt.RNG_COUNTER:
+            raise SystemExit("sample-range splitting needs the counter RNG")
+        w, h, spp = cfg["width"], cfg["height"], cfg["spp"]
+        r.upload(scene, accel)
+        accum = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+        r.set_accumulator(accum.data_ptr(), w, h)
+        p = rt.make_params(cam, w, h, spp, rng_mode=rng_mode, sample_begin=rank * spp)
+
+        def step(counted=False):
+            r.clear()  # memset + render are ordered on the library's own stream
+            r.render(p, counted=counted)
+            if world > 1:
+                r.synchronize()
+                dist.reduce(accum, dst=0)  # RCCL sum of the per-GPU accumulators onto rank 0
+                torch.cuda.current_stream().synchronize()  # before the next step clears the buffer
+
+        step(counted=True)
+        counters = r.counters()
+        units_per_step = w * h * spp * world
+        unit, metric = "Mpaths/s", "path-tracing throughput at %dx%d (Mpaths/s)" % (w, h)
+        algo_bytes = None
+        result["config"] = {"workload": f"{cfg['workload'].split(' ')[0]} scene {w}x{h}x{spp}spp depth50" if (args.width or args.height or args.spp) else cfg["workload"],
+                            "accel": args.accel, "spheres": scene.n_spheres, "rng": cfg["rng"],
+                            "lbvh_depth": r.lbvh_depth(), "global_samples_per_pixel": spp * world,
+                            "parallelism": f"sample ranges x{world} + RCCL reduce" if world > 1 else "single GPU"}
+        if accel == rt.ACCEL_LBVH:
+            result["lbvh_build_ms"] = r.last_build_ms()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # Timed region: exactly K steps between two barrier + synchronize pairs.
+    # Each launch is bracketed by HIP events recorded on the library's stream
+    # (rt_last_kernel_ms); reading them waits for that launch, which at one
+    # launch per step costs nothing the step would not wait for anyway.
+    per_launch = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        ms, kname = r.last_kernel_ms()
+        per_launch.append(ms)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    avg_kernel_ms = sum(per_launch) / len(per_launch)
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        flops = rt.algorithmic_flops(counters)
+        value = units_per_step * args.steps / elapsed / 1e6
+        achieved_tflops = flops / (avg_kernel_ms * 1e-3) / 1e12
+        result.update({
+            "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        })
+        if args.config == "c4":
+            result["roofline"] = {"bound": "hbm", "achieved": algo_bytes / (avg_kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": algo_bytes / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "traffic": None, "kernel": kname, "kernel_ms": avg_kernel_ms,
+                                  "valu_tflops": achieved_tflops, "valu_frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS}
+        else:
+            result["roofline"] = {"bound": "valu_fp32", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
+                                  "kernel": kname, "kernel_ms": avg_kernel_ms,
+                                  "algorithmic_gflop_per_launch": flops / 1e9}
+        result["counters_per_launch"] = counters
+        if not args.no_cpu_baseline and world == 1:
+            threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+            if args.config == "c4":
+                result["cpu_baseline"] = cpu_baseline_trace(rt, scene, threads, 0xC4C4C4C4)
+            else:
+                result["cpu_baseline"] = cpu_baseline_render(rt, scene, cam, cfg, threads)
+        print(json.dumps(result), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

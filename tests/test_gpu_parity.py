@@ -42,7 +42,7 @@ def rays_for(scene_id, n, seed):
 
 @pytest.mark.parametrize("accel", [rt.ACCEL_LINEAR, rt.ACCEL_LBVH])
 @pytest.mark.parametrize("scene_id,n_cloud", [(rt.SCENE_DEFAULT, 0), (rt.SCENE_RANDOM_SPHERES, 0), (rt.SCENE_PERLIN, 0),
-                                              (rt.SCENE_CLOUD, 3000)])
+                                              (rt.SCENE_CLOUD, 60000)])
 def test_trace_batch_matches_oracle(renderer, accel, scene_id, n_cloud):
     scene = rt.build_scene(scene_id, n=n_cloud, seed=0xC4C4C4C4)
     n = 4096
@@ -50,7 +50,7 @@ def test_trace_batch_matches_oracle(renderer, accel, scene_id, n_cloud):
     renderer.upload(scene, accel)
     ids, t, nrm = renderer.trace(o, d)
     oid, ot, onrm, _ = oracle.trace(scene, o, d, threads=8)
-    assert (oid >= 0).sum() > n // 20, "the batch should hit something"
+    assert (oid >= 0).sum() > n // 50, "the batch should hit something"
     assert np.array_equal(ids, oid), f"{(ids != oid).sum()} hit ids differ"
     assert_same_f32(t, ot, "t")
     assert_same_f32(nrm, onrm, "normal")
