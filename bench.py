@@ -167,14 +167,16 @@ def main():
         r.upload(scene, accel)
         accum = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
         r.set_accumulator(accum.data_ptr(), w, h)
-        p = rt.make_params(cam, w, h, spp, rng_mode=rng_mode, sample_begin=rank * spp)
+        from raytrace_amd import distributed as rtd
+        share = rtd.split_frame(h, spp * world, world)[rank]  # rank r: samples [r*spp, (r+1)*spp) of every pixel
+        p = rtd.apply_share(rt.make_params(cam, w, h, spp * world, rng_mode=rng_mode), share)
 
         def step(counted=False):
             r.clear()  # memset + render are ordered on the library's own stream
             r.render(p, counted=counted)
             if world > 1:
                 r.synchronize()
-                dist.reduce(accum, dst=0)  # RCCL sum of the per-GPU accumulators onto rank 0
+                rtd.combine(accum, dst=0)  # RCCL sum of the per-GPU accumulators onto rank 0
                 torch.cuda.current_stream().synchronize()  # before the next step clears the buffer
 
         step(counted=True)

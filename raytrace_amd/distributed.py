@@ -1,0 +1,52 @@
+"""Multi-GPU partitioning of a frame: image tiles x sample ranges, one process per GPU.
+
+Every path is independent, so a frame splits two ways: by pixel rows (disjoint pixels, nothing to combine but a
+gather) and by sample range (same pixels; the per-GPU FP32 accumulators must be summed).  With the counter RNG a
+sample's random stream depends on (seed, pixel, sample) only, so the image does not depend on the split.  The sum
+is one collective on the accumulator tensor: `torch.distributed.reduce` to the root, which on ROCm's "nccl"
+backend is RCCL over xGMI (the root receives world-1 partial images over its point-to-point links; nobody else
+needs the result, so no all-reduce).
+"""
+from dataclasses import dataclass
+
+
+@dataclass(frozen=True)
+class Share:
+    """What one rank renders: rows [y0,y1) of the image, samples [s0,s1) of each of their pixels."""
+    y0: int
+    y1: int
+    s0: int
+    s1: int
+
+
+def split_frame(height: int, samples: int, world: int, row_groups: int = 1):
+    """Shares of `world` ranks: `row_groups` bands of rows, each band's samples split over world/row_groups ranks."""
+    if world < 1 or row_groups < 1 or world % row_groups:
+        raise ValueError("world must be a positive multiple of row_groups")
+    per_band = world // row_groups
+    if samples < per_band:
+        raise ValueError("fewer samples than ranks per row band")
+    shares = []
+    for rank in range(world):
+        band, part = divmod(rank, per_band)
+        y0 = height * band // row_groups
+        y1 = height * (band + 1) // row_groups
+        s0 = samples * part // per_band
+        s1 = samples * (part + 1) // per_band
+        shares.append(Share(y0, y1, s0, s1))
+    return shares
+
+
+def apply_share(params, share: Share):
+    """Copy of an rt_params restricted to a share (tile rows and sample range)."""
+    p = params.copy()
+    p.tile_y0, p.tile_y1 = share.y0, share.y1
+    p.sample_begin, p.sample_end = share.s0, share.s1
+    return p
+
+
+def combine(accum, dst: int = 0, group=None):
+    """Sum the ranks' accumulators (a torch tensor, device or CPU) onto rank `dst`."""
+    import torch.distributed as dist
+    dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return accum
