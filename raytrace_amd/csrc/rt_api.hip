@@ -5,6 +5,7 @@
 
 #include <string.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -51,12 +52,26 @@ struct dev_buf {
     if (e == hipSuccess) n = count; else p = nullptr;
     return e;
   }
+  hipError_t upload(const std::vector<T>& v, hipStream_t st) {
+    hipError_t e = resize(v.empty() ? 1 : v.size());
+    if (e != hipSuccess || v.empty()) return e;
+    return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st);
+  }
   void release() {
     if (p) (void)hipFree(p);
     p = nullptr;
     n = 0;
   }
 };
+
+// Largest dynamic LDS a launch may ask for (the CU has 160 KiB).
+constexpr size_t kMaxLdsBytes = 160 * 1024;
+// A tree is staged in LDS when nodes + leaves fit in this many bytes.
+constexpr size_t kLdsTreeBudget = 64 * 1024;
+// Spheres with a radius above kBigFactor x the median radius stay out of the
+// tree (at most kMaxBig of them) and are tested exactly for every ray.
+constexpr float kBigFactor = 8.0f;
+constexpr int kMaxBig = 8;
 
 }  // namespace
 
@@ -71,15 +86,23 @@ struct rt_ctx {
   bool have_scene = false;
   int n_spheres = 0, n_materials = 0, accel = RT_ACCEL_LINEAR;
   dev_buf<float4> sph;
-  dev_buf<float> radius, inv_r;
+  dev_buf<float> inv_r;
   dev_buf<int32_t> sph_mat, mat_type;
   dev_buf<float4> mat_a;
-  // LBVH
-  dev_buf<bvh_node> nodes;
+  // hierarchy
+  int search = SEARCH_LINEAR;
+  int n_big = 0, n_leaf = 0, n_nodes = 0, root = 0, depth = 0;
+  dev_buf<float4> big_sph;
+  dev_buf<int32_t> big_idx;
+  dev_buf<float4> tree_sph;   // spheres of the tree, upload order among themselves
+  dev_buf<float> tree_r;
+  dev_buf<int32_t> tree_orig; // -> upload index
+  dev_buf<bvh4_node> nodes;
   dev_buf<float4> leaf_sph;
   dev_buf<float> leaf_r;
   dev_buf<int32_t> leaf_idx;
-  int root = 0, depth = 0;
+  float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
+  float r_max = 0.0f, r_median = 0.0f, abs_max = 0.0f;
 
   // accumulator
   dev_buf<float> accum_own;
@@ -88,6 +111,8 @@ struct rt_ctx {
   int samples_lo = 0, samples_hi = 0, samples_override = -1;
 
   dev_buf<uint32_t> seed_tex;
+  dev_buf<unsigned int> queue;
+  int n_cu = 0;
   dev_buf<unsigned long long> counters;
   dev_buf<float> out_linear;
   dev_buf<uint8_t> out_rgb8;
@@ -102,36 +127,48 @@ struct rt_ctx {
     s.sph_mat = sph_mat.p;
     s.mat_a = mat_a.p;
     s.mat_type = mat_type.p;
+    s.n_big = n_big;
+    s.big_sph = big_sph.p;
+    s.big_idx = big_idx.p;
+    s.n_leaf = n_leaf;
+    s.n_nodes = n_nodes;
     s.nodes = nodes.p;
     s.leaf_sph = leaf_sph.p;
     s.leaf_idx = leaf_idx.p;
     s.root = root;
+    for (int a = 0; a < 3; a++) {
+      s.root_lo[a] = root_lo[a];
+      s.root_hi[a] = root_hi[a];
+    }
+    s.r_max = r_max;
+    s.abs_max = abs_max;
     return s;
   }
-  bool use_bvh() const { return accel == RT_ACCEL_LBVH && n_spheres >= 1; }
-  int stack_depth() const { return depth <= 16 ? 16 : (depth <= 32 ? 32 : 64); }
 };
 
 namespace {
 
+// Builds the 4-wide LBVH over tree_sph / tree_r / tree_orig (n_leaf spheres).
 int build_lbvh(rt_ctx* c) {
-  const int n = c->n_spheres;
+  const int n = c->n_leaf;
   c->depth = 0;
+  c->n_nodes = 0;
   c->root = n == 1 ? ~0 : 0;
+  if (n == 0) return RT_OK;
   HIP_TRY(c->leaf_sph.resize((size_t)n));
   HIP_TRY(c->leaf_r.resize((size_t)n));
   HIP_TRY(c->leaf_idx.resize((size_t)n));
   HIP_TRY(c->nodes.resize((size_t)(n > 1 ? n - 1 : 1)));
 
   dev_buf<uint32_t> bounds, codes, codes_sorted, index, index_sorted;
-  dev_buf<int> child0, child1, node_parent, leaf_parent, max_depth;
+  dev_buf<int> child0, child1, node_parent, leaf_parent, scalars, slot_of;
   dev_buf<unsigned int> arrivals;
   dev_buf<float> node_box;
   dev_buf<unsigned char> temp;
   auto cleanup = [&]() {
     bounds.release(); codes.release(); codes_sorted.release(); index.release(); index_sorted.release();
-    child0.release(); child1.release(); node_parent.release(); leaf_parent.release(); max_depth.release();
-    arrivals.release(); node_box.release(); temp.release();
+    child0.release(); child1.release(); node_parent.release(); leaf_parent.release(); scalars.release();
+    slot_of.release(); arrivals.release(); node_box.release(); temp.release();
   };
 #define BUILD_TRY(expr)                                                                       \
   do {                                                                                        \
@@ -152,7 +189,8 @@ int build_lbvh(rt_ctx* c) {
   BUILD_TRY(child1.resize(ni));
   BUILD_TRY(node_parent.resize(ni));
   BUILD_TRY(leaf_parent.resize(nn));
-  BUILD_TRY(max_depth.resize(1));
+  BUILD_TRY(scalars.resize(2));  // [0] max depth, [1] 4-wide node counter
+  BUILD_TRY(slot_of.resize(ni));
   BUILD_TRY(arrivals.resize(ni));
   BUILD_TRY(node_box.resize(6 * ni));
   size_t temp_bytes = 0;
@@ -163,34 +201,83 @@ int build_lbvh(rt_ctx* c) {
   hipStream_t st = c->stream;
   const unsigned blocks_n = (unsigned)((nn + 255) / 256);
   const unsigned blocks_i = (unsigned)((ni + 255) / 256);
+  const int one = 1;
   BUILD_TRY(hipEventRecord(c->ev_b0, st));
   BUILD_TRY(hipMemsetAsync(bounds.p, 0xFF, 3 * sizeof(uint32_t), st));
   BUILD_TRY(hipMemsetAsync(bounds.p + 3, 0x00, 3 * sizeof(uint32_t), st));
   BUILD_TRY(hipMemsetAsync(arrivals.p, 0, ni * sizeof(unsigned int), st));
-  BUILD_TRY(hipMemsetAsync(max_depth.p, 0, sizeof(int), st));
+  BUILD_TRY(hipMemsetAsync(scalars.p, 0, sizeof(int), st));
+  BUILD_TRY(hipMemcpyAsync(scalars.p + 1, &one, sizeof(int), hipMemcpyHostToDevice, st));
   BUILD_TRY(hipMemsetAsync(leaf_parent.p, 0xFF, nn * sizeof(int), st));  // -1: a lone leaf has no parent
-  lbvh_bounds_kernel<<<blocks_n < 1024u ? blocks_n : 1024u, 256, 0, st>>>(c->sph.p, n, bounds.p);
-  lbvh_morton_kernel<<<blocks_n, 256, 0, st>>>(c->sph.p, n, bounds.p, codes.p, index.p);
+  lbvh_bounds_kernel<<<blocks_n < 1024u ? blocks_n : 1024u, 256, 0, st>>>(c->tree_sph.p, n, bounds.p);
+  lbvh_morton_kernel<<<blocks_n, 256, 0, st>>>(c->tree_sph.p, n, bounds.p, codes.p, index.p);
   BUILD_TRY(rocprim::radix_sort_pairs(temp.p, temp_bytes, codes.p, codes_sorted.p, index.p, index_sorted.p, nn, 0, 30, st));
-  lbvh_gather_kernel<<<blocks_n, 256, 0, st>>>(c->sph.p, c->radius.p, index_sorted.p, n, c->leaf_sph.p, c->leaf_r.p,
-                                               c->leaf_idx.p);
+  lbvh_gather_kernel<<<blocks_n, 256, 0, st>>>(c->tree_sph.p, c->tree_r.p, c->tree_orig.p, index_sorted.p, n, c->leaf_sph.p,
+                                               c->leaf_r.p, c->leaf_idx.p);
   if (n > 1) {
     lbvh_hierarchy_kernel<<<blocks_i, 256, 0, st>>>(codes_sorted.p, n, child0.p, child1.p, node_parent.p, leaf_parent.p);
     lbvh_fit_kernel<<<blocks_n, 256, 0, st>>>(c->leaf_sph.p, c->leaf_r.p, n, child0.p, child1.p, node_parent.p,
-                                              leaf_parent.p, node_box.p, arrivals.p, max_depth.p);
-    lbvh_pack_kernel<<<blocks_i, 256, 0, st>>>(c->leaf_sph.p, c->leaf_r.p, n, child0.p, child1.p, node_box.p, c->nodes.p);
+                                              leaf_parent.p, node_box.p, arrivals.p, scalars.p);
+    lbvh_mark_kernel<<<blocks_i, 256, 0, st>>>(n - 1, node_parent.p, slot_of.p, scalars.p + 1);
+    lbvh_collapse_kernel<<<blocks_i, 256, 0, st>>>(c->leaf_sph.p, c->leaf_r.p, n - 1, child0.p, child1.p, node_box.p,
+                                                   slot_of.p, c->nodes.p);
   }
   BUILD_TRY(hipGetLastError());
   BUILD_TRY(hipEventRecord(c->ev_b1, st));
-  int depth = 0;
-  BUILD_TRY(hipMemcpyAsync(&depth, max_depth.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  int sc[2] = {0, 0};
+  float rb[6] = {0, 0, 0, 0, 0, 0};
+  BUILD_TRY(hipMemcpyAsync(sc, scalars.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  if (n > 1) BUILD_TRY(hipMemcpyAsync(rb, node_box.p, 6 * sizeof(float), hipMemcpyDeviceToHost, st));
+  float4 only;
+  float only_r = 0.0f;
+  if (n == 1) {
+    BUILD_TRY(hipMemcpyAsync(&only, c->leaf_sph.p, sizeof(float4), hipMemcpyDeviceToHost, st));
+    BUILD_TRY(hipMemcpyAsync(&only_r, c->leaf_r.p, sizeof(float), hipMemcpyDeviceToHost, st));
+  }
   BUILD_TRY(hipStreamSynchronize(st));
   cleanup();
 #undef BUILD_TRY
-  c->depth = depth;
+  if (n == 1) {
+    const float r = std::fabs(only_r);
+    rb[0] = only.x - r; rb[1] = only.y - r; rb[2] = only.z - r;
+    rb[3] = only.x + r; rb[4] = only.y + r; rb[5] = only.z + r;
+  }
+  c->depth = sc[0];
+  c->n_nodes = n > 1 ? sc[1] : 0;
+  c->abs_max = 0.0f;
+  for (int a = 0; a < 3; a++) {
+    c->root_lo[a] = rb[a];
+    c->root_hi[a] = rb[3 + a];
+    c->abs_max += std::fmax(std::fabs(rb[a]), std::fabs(rb[3 + a]));
+  }
   c->have_build_time = true;
-  if (depth > 64) return fail(RT_ERR_STATE, "LBVH depth %d exceeds the traversal stack (64)", depth);
   return RT_OK;
+}
+
+// Which search the kernels use for the uploaded scene.
+int choose_search(const rt_ctx* c) {
+  if (c->accel != RT_ACCEL_LBVH || c->n_spheres < 1) return SEARCH_LINEAR;
+  bool pad_ray = true;
+  if (c->n_leaf > 0) {
+    // One pad per ray is worth it when the worst pad (ray origin about one
+    // scene extent away) stays below the typical radius.
+    const float extent = (c->root_hi[0] - c->root_lo[0]) + (c->root_hi[1] - c->root_lo[1]) + (c->root_hi[2] - c->root_lo[2]);
+    pad_ray = RT_PAD_SCALE * extent < c->r_median;
+  }
+  const size_t tree_bytes = (size_t)c->n_nodes * sizeof(bvh4_node) + (size_t)c->n_leaf * 20 + 16;
+  const bool lds = c->n_nodes <= 4096 && tree_bytes <= kLdsTreeBudget;
+  if (lds) return pad_ray ? SEARCH_TREE_LDS_RAY : SEARCH_TREE_LDS_NODE;
+  return pad_ray ? SEARCH_TREE_GLB_RAY : SEARCH_TREE_GLB_NODE;
+}
+
+const char* search_name(int search, bool render) {
+  switch (search) {
+    case SEARCH_LINEAR: return render ? "rt_render_kernel<linear>" : "rt_trace_kernel<linear>";
+    case SEARCH_TREE_LDS_RAY: return render ? "rt_render_kernel<lbvh4,lds,pad_ray>" : "rt_trace_kernel<lbvh4,lds,pad_ray>";
+    case SEARCH_TREE_LDS_NODE: return render ? "rt_render_kernel<lbvh4,lds,pad_node>" : "rt_trace_kernel<lbvh4,lds,pad_node>";
+    case SEARCH_TREE_GLB_RAY: return render ? "rt_render_kernel<lbvh4,hbm,pad_ray>" : "rt_trace_kernel<lbvh4,hbm,pad_ray>";
+    default: return render ? "rt_render_kernel<lbvh4,hbm,pad_node>" : "rt_trace_kernel<lbvh4,hbm,pad_node>";
+  }
 }
 
 int check_ctx(rt_ctx* c) {
@@ -213,32 +300,57 @@ int check_params(rt_ctx* c, const rt_params* p) {
   return RT_OK;
 }
 
-template <int ACCEL, int RNG, bool COUNTED>
-void launch_render_stack(int stack, dim3 grid, hipStream_t st, const render_args& a) {
-  if (ACCEL != RT_ACCEL_LBVH || stack == 16)
-    rt_render_kernel<ACCEL, RNG, COUNTED, 16><<<grid, 256, 0, st>>>(a);
-  else if (stack == 32)
-    rt_render_kernel<ACCEL, RNG, COUNTED, 32><<<grid, 256, 0, st>>>(a);
-  else
-    rt_render_kernel<ACCEL, RNG, COUNTED, 64><<<grid, 256, 0, st>>>(a);
+template <typename K>
+hipError_t allow_lds(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int ACCEL, bool COUNTED>
-void launch_render_rng(int rng, int stack, dim3 grid, hipStream_t st, const render_args& a) {
-  if (rng == RT_RNG_XORSHIFT_REF)
-    launch_render_stack<ACCEL, RT_RNG_XORSHIFT_REF, COUNTED>(stack, grid, st, a);
-  else
-    launch_render_stack<ACCEL, RT_RNG_COUNTER, COUNTED>(stack, grid, st, a);
+// Persistent launch: as many workgroups as the chip keeps resident (fewer when
+// the image has fewer 8x8 tiles than that).
+template <int SEARCH, int RNG, bool COUNTED>
+hipError_t launch_render_one(const rt_ctx* c, const rt_params* p, hipStream_t st, const render_args& a) {
+  using T = search_traits<SEARCH>;
+  const int tw = p->tile_x1 - p->tile_x0, th = p->tile_y1 - p->tile_y0;
+  const size_t lds = search_lds_bytes<SEARCH>(c->n_nodes, c->n_leaf);
+  hipError_t e = allow_lds(rt_render_kernel<SEARCH, RNG, COUNTED>, lds);
+  if (e != hipSuccess) return e;
+  int per_cu = 0;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_kernel<SEARCH, RNG, COUNTED>, T::threads, lds);
+  if (e != hipSuccess) return e;
+  if (per_cu < 1) per_cu = 1;
+  const long long tiles = (long long)((tw + 7) / 8) * ((th + 7) / 8);
+  long long blocks = (long long)per_cu * c->n_cu;
+  const long long needed = (tiles + T::waves - 1) / T::waves;
+  if (blocks > needed) blocks = needed;
+  if (blocks < 1) blocks = 1;
+  rt_render_kernel<SEARCH, RNG, COUNTED><<<dim3((unsigned)blocks), T::threads, lds, st>>>(a);
+  return hipGetLastError();
 }
 
-template <int ACCEL, bool COUNTED>
-void launch_trace_stack(int stack, unsigned blocks, hipStream_t st, const trace_args& a) {
-  if (ACCEL != RT_ACCEL_LBVH || stack == 16)
-    rt_trace_kernel<ACCEL, COUNTED, 16><<<blocks, 256, 0, st>>>(a);
-  else if (stack == 32)
-    rt_trace_kernel<ACCEL, COUNTED, 32><<<blocks, 256, 0, st>>>(a);
-  else
-    rt_trace_kernel<ACCEL, COUNTED, 64><<<blocks, 256, 0, st>>>(a);
+template <int SEARCH>
+hipError_t launch_render(const rt_ctx* c, const rt_params* p, bool counted, hipStream_t st, const render_args& a) {
+  if (p->rng_mode == RT_RNG_XORSHIFT_REF)
+    return counted ? launch_render_one<SEARCH, RT_RNG_XORSHIFT_REF, true>(c, p, st, a)
+                   : launch_render_one<SEARCH, RT_RNG_XORSHIFT_REF, false>(c, p, st, a);
+  return counted ? launch_render_one<SEARCH, RT_RNG_COUNTER, true>(c, p, st, a)
+                 : launch_render_one<SEARCH, RT_RNG_COUNTER, false>(c, p, st, a);
+}
+
+template <int SEARCH, bool COUNTED>
+hipError_t launch_trace_one(const rt_ctx* c, hipStream_t st, const trace_args& a) {
+  using T = search_traits<SEARCH>;
+  const unsigned blocks = (unsigned)((a.n + T::threads - 1) / T::threads);
+  const size_t lds = search_lds_bytes<SEARCH>(c->n_nodes, c->n_leaf);
+  hipError_t e = allow_lds(rt_trace_kernel<SEARCH, COUNTED>, lds);
+  if (e != hipSuccess) return e;
+  rt_trace_kernel<SEARCH, COUNTED><<<blocks, T::threads, lds, st>>>(a);
+  return hipGetLastError();
+}
+
+template <int SEARCH>
+hipError_t launch_trace(const rt_ctx* c, bool counted, hipStream_t st, const trace_args& a) {
+  return counted ? launch_trace_one<SEARCH, true>(c, st, a) : launch_trace_one<SEARCH, false>(c, st, a);
 }
 
 int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
@@ -274,6 +386,8 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   a.accum = c->accum();
   a.seed_tex = nullptr;
   a.counters = nullptr;
+  HIP_TRY(c->queue.resize(1));
+  a.queue = c->queue.p;
   if (p->rng_mode == RT_RNG_XORSHIFT_REF && p->seed_tex) {
     HIP_TRY(c->seed_tex.resize(n_px));
     HIP_TRY(hipMemcpyAsync(c->seed_tex.p, p->seed_tex, n_px * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
@@ -286,20 +400,18 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   }
   const int tw = p->tile_x1 - p->tile_x0, th = p->tile_y1 - p->tile_y0;
   if (tw == 0 || th == 0 || p->sample_end == p->sample_begin) return RT_OK;
-  dim3 grid((unsigned)((tw + 15) / 16), (unsigned)((th + 15) / 16));
-  const bool bvh = c->use_bvh();
-  const int stack = c->stack_depth();
+  HIP_TRY(hipMemsetAsync(c->queue.p, 0, sizeof(unsigned int), c->stream));
   HIP_TRY(hipEventRecord(c->ev_k0, c->stream));
-  if (bvh) {
-    if (counted) launch_render_rng<RT_ACCEL_LBVH, true>(p->rng_mode, stack, grid, c->stream, a);
-    else launch_render_rng<RT_ACCEL_LBVH, false>(p->rng_mode, stack, grid, c->stream, a);
-    c->last_kernel = "rt_render_kernel<lbvh>";
-  } else {
-    if (counted) launch_render_rng<RT_ACCEL_LINEAR, true>(p->rng_mode, stack, grid, c->stream, a);
-    else launch_render_rng<RT_ACCEL_LINEAR, false>(p->rng_mode, stack, grid, c->stream, a);
-    c->last_kernel = "rt_render_kernel<linear>";
+  hipError_t e;
+  switch (c->search) {
+    case SEARCH_TREE_LDS_RAY: e = launch_render<SEARCH_TREE_LDS_RAY>(c, p, counted, c->stream, a); break;
+    case SEARCH_TREE_LDS_NODE: e = launch_render<SEARCH_TREE_LDS_NODE>(c, p, counted, c->stream, a); break;
+    case SEARCH_TREE_GLB_RAY: e = launch_render<SEARCH_TREE_GLB_RAY>(c, p, counted, c->stream, a); break;
+    case SEARCH_TREE_GLB_NODE: e = launch_render<SEARCH_TREE_GLB_NODE>(c, p, counted, c->stream, a); break;
+    default: e = launch_render<SEARCH_LINEAR>(c, p, counted, c->stream, a); break;
   }
-  HIP_TRY(hipGetLastError());
+  if (e != hipSuccess) return fail(RT_ERR_DEVICE, "render launch: %s", hipGetErrorString(e));
+  c->last_kernel = search_name(c->search, true);
   HIP_TRY(hipEventRecord(c->ev_k1, c->stream));
   c->have_kernel_time = true;
   return RT_OK;
@@ -329,6 +441,9 @@ int rt_init(int device, rt_ctx** out) {
   HIP_TRY(hipSetDevice(device));
   rt_ctx* c = new rt_ctx();
   c->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+  if (c->n_cu < 1) c->n_cu = 256;
   hipError_t err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (err == hipSuccess) err = hipEventCreate(&c->ev_k0);
   if (err == hipSuccess) err = hipEventCreate(&c->ev_k1);
@@ -346,9 +461,10 @@ void rt_destroy(rt_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  c->sph.release(); c->radius.release(); c->inv_r.release(); c->sph_mat.release(); c->mat_type.release();
-  c->mat_a.release(); c->nodes.release(); c->leaf_sph.release(); c->leaf_r.release(); c->leaf_idx.release();
-  c->accum_own.release(); c->seed_tex.release(); c->counters.release(); c->out_linear.release(); c->out_rgb8.release();
+  c->sph.release(); c->inv_r.release(); c->sph_mat.release(); c->mat_type.release(); c->mat_a.release();
+  c->big_sph.release(); c->big_idx.release(); c->tree_sph.release(); c->tree_r.release(); c->tree_orig.release();
+  c->nodes.release(); c->leaf_sph.release(); c->leaf_r.release(); c->leaf_idx.release();
+  c->accum_own.release(); c->seed_tex.release(); c->queue.release(); c->counters.release(); c->out_linear.release(); c->out_rgb8.release();
   if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
   if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
   if (c->ev_b0) (void)hipEventDestroy(c->ev_b0);
@@ -398,32 +514,74 @@ int rt_scene_upload(rt_ctx* c, const void* spheres_std140, int n_spheres, const 
     mat_type[i] = type;
     mat_a[i] = make_float4(alb[0], alb[1], alb[2], param1);
   }
-  const size_t ns1 = ns ? ns : 1, nm1 = nm ? nm : 1;
-  HIP_TRY(c->sph.resize(ns1));
-  HIP_TRY(c->radius.resize(ns1));
-  HIP_TRY(c->inv_r.resize(ns1));
-  HIP_TRY(c->sph_mat.resize(ns1));
-  HIP_TRY(c->mat_type.resize(nm1));
-  HIP_TRY(c->mat_a.resize(nm1));
-  if (ns) {
-    HIP_TRY(hipMemcpyAsync(c->sph.p, sph.data(), ns * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->radius.p, radius.data(), ns * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->inv_r.p, inv_r.data(), ns * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->sph_mat.p, sph_mat.data(), ns * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c->sph.upload(sph, c->stream));
+  HIP_TRY(c->inv_r.upload(inv_r, c->stream));
+  HIP_TRY(c->sph_mat.upload(sph_mat, c->stream));
+  HIP_TRY(c->mat_type.upload(mat_type, c->stream));
+  HIP_TRY(c->mat_a.upload(mat_a, c->stream));
+
+  // Hierarchy input: the few spheres far larger than the rest go to an exact
+  // pre-test list, the others into the tree.
+  std::vector<float4> big_sph, tree_sph;
+  std::vector<int32_t> big_idx, tree_orig;
+  std::vector<float> tree_r;
+  c->r_max = c->r_median = 0.0f;
+  if (accel == RT_ACCEL_LBVH && ns > 0) {
+    std::vector<float> absr(ns);
+    for (size_t i = 0; i < ns; i++) absr[i] = std::fabs(radius[i]);
+    std::vector<float> sorted = absr;
+    std::nth_element(sorted.begin(), sorted.begin() + ns / 2, sorted.end());
+    const float median = sorted[ns / 2];
+    std::vector<size_t> cand;
+    for (size_t i = 0; i < ns; i++)
+      if (absr[i] > kBigFactor * median || !(absr[i] < 3.0e37f)) cand.push_back(i);
+    if ((int)cand.size() > kMaxBig) {  // keep only the largest ones out of the tree
+      std::partial_sort(cand.begin(), cand.begin() + kMaxBig, cand.end(), [&](size_t x, size_t y) { return absr[x] > absr[y]; });
+      cand.resize(kMaxBig);
+      std::sort(cand.begin(), cand.end());
+    }
+    std::vector<char> is_big(ns, 0);
+    for (size_t i : cand) is_big[i] = 1;
+    std::vector<float> tree_abs;
+    for (size_t i = 0; i < ns; i++) {
+      if (is_big[i]) {
+        big_sph.push_back(sph[i]);
+        big_idx.push_back((int32_t)i);
+      } else {
+        tree_sph.push_back(sph[i]);
+        tree_r.push_back(radius[i]);
+        tree_orig.push_back((int32_t)i);
+        tree_abs.push_back(absr[i]);
+        c->r_max = std::fmax(c->r_max, absr[i]);
+      }
+    }
+    if (!tree_abs.empty()) {
+      std::nth_element(tree_abs.begin(), tree_abs.begin() + tree_abs.size() / 2, tree_abs.end());
+      c->r_median = tree_abs[tree_abs.size() / 2];
+    }
   }
-  if (nm) {
-    HIP_TRY(hipMemcpyAsync(c->mat_type.p, mat_type.data(), nm * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->mat_a.p, mat_a.data(), nm * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-  }
+  HIP_TRY(c->big_sph.upload(big_sph, c->stream));
+  HIP_TRY(c->big_idx.upload(big_idx, c->stream));
+  HIP_TRY(c->tree_sph.upload(tree_sph, c->stream));
+  HIP_TRY(c->tree_r.upload(tree_r, c->stream));
+  HIP_TRY(c->tree_orig.upload(tree_orig, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));  // the host vectors go out of scope
   c->n_spheres = n_spheres;
   c->n_materials = n_materials;
   c->accel = accel;
+  c->n_big = (int)big_sph.size();
+  c->n_leaf = (int)tree_sph.size();
+  c->n_nodes = 0;
+  c->depth = 0;
   c->have_build_time = false;
-  if (accel == RT_ACCEL_LBVH && n_spheres >= 1) {
+  if (accel == RT_ACCEL_LBVH && c->n_leaf > 0) {
     rc = build_lbvh(c);
     if (rc) return rc;
   }
+  c->search = choose_search(c);
+  if (search_lds_bytes<SEARCH_TREE_LDS_RAY>(c->n_nodes, c->n_leaf) > kMaxLdsBytes &&
+      (c->search == SEARCH_TREE_LDS_RAY || c->search == SEARCH_TREE_LDS_NODE))
+    return fail(RT_ERR_STATE, "internal: LDS tree does not fit");
   c->have_scene = true;
   return RT_OK;
 }
@@ -508,19 +666,17 @@ int rt_trace_batch_device(rt_ctx* c, const float* o_xyz, const float* d_xyz, siz
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(rt_counters), c->stream));
     a.counters = c->counters.p;
   }
-  const unsigned blocks = (unsigned)((n + 255) / 256);
-  const int stack = c->stack_depth();
   HIP_TRY(hipEventRecord(c->ev_k0, c->stream));
-  if (c->use_bvh()) {
-    if (counted) launch_trace_stack<RT_ACCEL_LBVH, true>(stack, blocks, c->stream, a);
-    else launch_trace_stack<RT_ACCEL_LBVH, false>(stack, blocks, c->stream, a);
-    c->last_kernel = "rt_trace_kernel<lbvh>";
-  } else {
-    if (counted) launch_trace_stack<RT_ACCEL_LINEAR, true>(stack, blocks, c->stream, a);
-    else launch_trace_stack<RT_ACCEL_LINEAR, false>(stack, blocks, c->stream, a);
-    c->last_kernel = "rt_trace_kernel<linear>";
+  hipError_t e;
+  switch (c->search) {
+    case SEARCH_TREE_LDS_RAY: e = launch_trace<SEARCH_TREE_LDS_RAY>(c, counted != 0, c->stream, a); break;
+    case SEARCH_TREE_LDS_NODE: e = launch_trace<SEARCH_TREE_LDS_NODE>(c, counted != 0, c->stream, a); break;
+    case SEARCH_TREE_GLB_RAY: e = launch_trace<SEARCH_TREE_GLB_RAY>(c, counted != 0, c->stream, a); break;
+    case SEARCH_TREE_GLB_NODE: e = launch_trace<SEARCH_TREE_GLB_NODE>(c, counted != 0, c->stream, a); break;
+    default: e = launch_trace<SEARCH_LINEAR>(c, counted != 0, c->stream, a); break;
   }
-  HIP_TRY(hipGetLastError());
+  if (e != hipSuccess) return fail(RT_ERR_DEVICE, "trace launch: %s", hipGetErrorString(e));
+  c->last_kernel = search_name(c->search, false);
   HIP_TRY(hipEventRecord(c->ev_k1, c->stream));
   c->have_kernel_time = true;
   return RT_OK;
@@ -597,8 +753,6 @@ int rt_last_build_ms(rt_ctx* c, float* ms) {
   return RT_OK;
 }
 
-/* Depth of the LBVH of the uploaded scene (largest number of ancestors of a
- * leaf); 0 for the linear scan. */
 int rt_lbvh_depth(rt_ctx* c) { return c ? c->depth : 0; }
 
 }  // extern "C"

@@ -247,12 +247,20 @@ struct hit_rec {
 };
 
 // material_shade, fs:225-289.  Returns whether the path continues
-// (ray.bounce); updates dir and albedo.
+// (ray.bounce); updates dir and albedo.  The lambertian, perlin-lambertian and
+// metallic branches all start with one random_unit_vector: it is drawn once,
+// ahead of the branch, so that lanes with different materials share the
+// rejection loop (each lane's own draw sequence is unchanged).
 template <int RNG, bool COUNTED>
 RT_DEV bool shade_hit(const hit_rec& h, int type, float param1, f3 m_albedo, f3& dir, f3& albedo, uint32_t& rng,
                       lane_counters& k) {
-  if (type == RT_MAT_LAMBERTIAN || type == RT_MAT_PERLIN_LAMBERTIAN) {  // fs:243-252
-    f3 nd = h.normal + random_on_hemisphere<RNG, COUNTED>(rng, h.normal, k);
+  const bool diffuse = type == RT_MAT_LAMBERTIAN || type == RT_MAT_PERLIN_LAMBERTIAN;
+  const bool metal = type == RT_MAT_METALLIC;
+  f3 ruv = mk3(0.0f, 0.0f, 0.0f);
+  if (diffuse || metal) ruv = random_unit_vector<RNG, COUNTED>(rng, k);
+  if (diffuse) {  // fs:243-252, random_on_hemisphere fs:385-392
+    if (!(dot3(ruv, h.normal) >= 0.0f)) ruv = -ruv;
+    f3 nd = h.normal + ruv;
     if (near_zero3(nd)) nd = h.normal;
     dir = nd;
     if (type == RT_MAT_LAMBERTIAN) {
@@ -265,10 +273,10 @@ RT_DEV bool shade_hit(const hit_rec& h, int type, float param1, f3 m_albedo, f3&
     }
     return true;
   }
-  if (type == RT_MAT_METALLIC) {  // fs:254-265
+  if (metal) {  // fs:254-265
     RT_COUNT(k, metallic, 1);
     f3 r = reflect3(dir, normalize3(h.normal));
-    r = normalize3(r) + (param1 * random_unit_vector<RNG, COUNTED>(rng, k));
+    r = normalize3(r) + (param1 * ruv);
     dir = r;
     albedo = albedo * m_albedo;
     bool go = dot3(r, h.normal) > 0.0f;

@@ -1,7 +1,8 @@
 // rt_lbvh.cuh — GPU construction of the linear bounding volume hierarchy:
 // scene bounds -> 30-bit Morton codes of the sphere centres -> radix sort ->
-// Karras-style radix tree over the sorted codes -> bottom-up box fit -> 64-byte
-// traversal nodes.  The reference has no counterpart (it scans every sphere,
+// Karras-style radix tree over the sorted codes -> bottom-up box fit -> collapse
+// of every two levels into 128-byte 4-wide traversal nodes.
+// The reference has no counterpart (it scans every sphere,
 // testFragment.fs:176-184); the hierarchy is checked against that scan.
 #pragma once
 
@@ -125,14 +126,15 @@ __device__ __forceinline__ box3 sphere_box(const float4* leaf_sph, const float* 
 }
 
 // Gather the spheres into Morton order.
-__global__ __launch_bounds__(256) void lbvh_gather_kernel(const float4* sph, const float* radius, const uint32_t* sorted_index,
-                                                          int n, float4* leaf_sph, float* leaf_r, int32_t* leaf_idx) {
+__global__ __launch_bounds__(256) void lbvh_gather_kernel(const float4* sph, const float* radius, const int32_t* upload_index,
+                                                          const uint32_t* sorted_index, int n, float4* leaf_sph,
+                                                          float* leaf_r, int32_t* leaf_idx) {
   const int kpos = blockIdx.x * 256 + threadIdx.x;
   if (kpos >= n) return;
   const uint32_t src = sorted_index[kpos];
   leaf_sph[kpos] = sph[src];
   leaf_r[kpos] = radius[src];
-  leaf_idx[kpos] = (int32_t)src;
+  leaf_idx[kpos] = upload_index[src];
 }
 
 // One thread per leaf climbs towards the root; at each node the first arrival
@@ -191,33 +193,66 @@ __global__ __launch_bounds__(256) void lbvh_fit_kernel(const float4* leaf_sph, c
   }
 }
 
-// Traversal nodes: each internal node carries its two children's boxes.
-__global__ __launch_bounds__(256) void lbvh_pack_kernel(const float4* leaf_sph, const float* leaf_r, int n, const int* child0,
-                                                        const int* child1, const float* node_box, bvh_node* nodes) {
+// ---- collapse to a 4-wide tree ----------------------------------------------
+// Binary nodes at even depth become 4-wide nodes whose children are their
+// grandchildren (or children, where a child is a leaf).
+
+// slot_of[i] = index of the 4-wide node made from binary node i, or -1.
+// counter starts at 1: the root keeps slot 0.
+__global__ __launch_bounds__(256) void lbvh_mark_kernel(int n_internal, const int* node_parent, int* slot_of, int* counter) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n - 1) return;
-  bvh_node nd;
-  nd.c0 = child0[i];
-  nd.c1 = child1[i];
-  nd.pad[0] = nd.pad[1] = 0;
+  if (i >= n_internal) return;
+  int depth = 0;
+  for (int p = node_parent[i]; p >= 0; p = node_parent[p]) depth++;
+  int slot = -1;
+  if ((depth & 1) == 0) slot = (i == 0) ? 0 : atomicAdd(counter, 1);
+  slot_of[i] = slot;
+}
+
+__global__ __launch_bounds__(256) void lbvh_collapse_kernel(const float4* leaf_sph, const float* leaf_r, int n_internal,
+                                                            const int* child0, const int* child1, const float* node_box,
+                                                            const int* slot_of, bvh4_node* nodes) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_internal) return;
+  const int slot = slot_of[i];
+  if (slot < 0) return;
+  int kids[4];
+  int nk = 0;
 #pragma unroll
   for (int side = 0; side < 2; side++) {
-    const int c = side == 0 ? nd.c0 : nd.c1;
-    box3 cb;
+    const int c = side == 0 ? child0[i] : child1[i];
     if (c < 0) {
-      cb = sphere_box(leaf_sph, leaf_r, ~c);
-    } else {
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-        cb.lo[a] = node_box[6 * (size_t)c + a];
-        cb.hi[a] = node_box[6 * (size_t)c + 3 + a];
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      if (side == 0) { nd.lo0[a] = cb.lo[a]; nd.hi0[a] = cb.hi[a]; }
-      else           { nd.lo1[a] = cb.lo[a]; nd.hi1[a] = cb.hi[a]; }
+      kids[nk++] = c;
+    } else {  // odd-depth binary node: pass its children up
+      kids[nk++] = child0[c];
+      kids[nk++] = child1[c];
     }
   }
-  nodes[i] = nd;
+  bvh4_node nd;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    nd.pad[s] = 0;
+    if (s < nk) {
+      const int c = kids[s];
+      box3 b;
+      if (c < 0) {
+        b = sphere_box(leaf_sph, leaf_r, ~c);
+        nd.ref[s] = c;
+      } else {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          b.lo[a] = node_box[6 * (size_t)c + a];
+          b.hi[a] = node_box[6 * (size_t)c + 3 + a];
+        }
+        nd.ref[s] = slot_of[c];
+      }
+      nd.lox[s] = b.lo[0]; nd.loy[s] = b.lo[1]; nd.loz[s] = b.lo[2];
+      nd.hix[s] = b.hi[0]; nd.hiy[s] = b.hi[1]; nd.hiz[s] = b.hi[2];
+    } else {  // unused slot: a far-away point box, and a reference no test accepts
+      nd.lox[s] = nd.loy[s] = nd.loz[s] = 3.0e38f;
+      nd.hix[s] = nd.hiy[s] = nd.hiz[s] = 3.0e38f;
+      nd.ref[s] = RT_REF_EMPTY;
+    }
+  }
+  nodes[slot] = nd;
 }

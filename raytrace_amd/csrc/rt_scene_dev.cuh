@@ -1,33 +1,45 @@
 // rt_scene_dev.cuh — device views of an uploaded scene and the two closest-hit
-// searches over it: the reference's linear scan and the LBVH traversal.
+// searches over it: the reference's linear scan and the 4-wide LBVH traversal.
 #pragma once
 
 #include "rt_device.cuh"
 
-// One LBVH node: the boxes of its two children and their references.
-// A reference >= 0 is an internal node index; < 0 is a leaf, ~ref = position of
-// the sphere in Morton order.  64 bytes, fetched as four 16-byte loads.
-struct __attribute__((aligned(64))) bvh_node {
-  float lo0[3], hi0[3];
-  float lo1[3], hi1[3];
-  int32_t c0, c1;
-  int32_t pad[2];
+// One node of the 4-wide hierarchy (two levels of the binary LBVH collapsed):
+// the boxes of up to four children, component-wise so that one 16-byte load
+// brings the same plane of all four, and their references.
+// ref >= 0: child node index; RT_REF_EMPTY: unused slot; otherwise a leaf,
+// ~ref = position of the sphere in Morton order.  128 bytes.
+#define RT_REF_EMPTY ((int32_t)0x80000000)
+struct __attribute__((aligned(16))) bvh4_node {
+  float lox[4], loy[4], loz[4];
+  float hix[4], hiy[4], hiz[4];
+  int32_t ref[4];
+  int32_t pad[4];
 };
 
 struct scene_dev {
-  int32_t n_spheres;
+  int32_t n_spheres;    // all spheres, upload order
   int32_t n_materials;
-  // upload order
-  const float4* sph;       // (cx, cy, cz, r*r)
-  const float* inv_r;      // 1 / r
-  const int32_t* sph_mat;  // material slot
-  const float4* mat_a;     // (albedo.r, albedo.g, albedo.b, param1)
+  const float4* sph;        // (cx, cy, cz, r*r), upload order: linear scan and hit record
+  const float* inv_r;       // 1 / r
+  const int32_t* sph_mat;   // material slot
+  const float4* mat_a;      // (albedo.r, albedo.g, albedo.b, param1)
   const int32_t* mat_type;
-  // LBVH (null for the linear scan)
-  const bvh_node* nodes;
-  const float4* leaf_sph;   // Morton order: (cx, cy, cz, r*r)
+  // --- hierarchy (unused by the linear scan) ---
+  // Spheres much larger than the rest are kept out of the tree and tested
+  // exactly for every ray: their boxes would swallow the whole tree.
+  int32_t n_big;
+  const float4* big_sph;    // (cx, cy, cz, r*r)
+  const int32_t* big_idx;   // upload index, ascending
+  int32_t n_leaf;           // spheres in the tree
+  int32_t n_nodes;          // 4-wide nodes
+  const bvh4_node* nodes;
+  const float4* leaf_sph;   // Morton order
   const int32_t* leaf_idx;  // Morton position -> upload index
-  int32_t root;             // reference of the root
+  int32_t root;             // reference of the root (a leaf reference when n_leaf == 1)
+  float root_lo[3], root_hi[3];  // bounds of the tree's spheres
+  float r_max;              // largest radius in the tree
+  float abs_max;            // largest |coordinate| sum of the root box corners
 };
 
 // ---------------------------------------------------------------------------
@@ -61,143 +73,278 @@ RT_DEV void hit_linear(const scene_dev& sc, f3 o, f3 d, float& t_out, int& i_out
 }
 
 // ---------------------------------------------------------------------------
-// LBVH traversal.
+// Hierarchy traversal.
 //
 // The search must return exactly what the linear scan returns, including hits
 // that exist only because of binary32 rounding in the sphere test: the computed
 // discriminant differs from the exact one by at most a*(19u*|oc|^2 + 6u*r^2),
 // u = 2^-24, so a ray can "hit" a sphere whose true distance from the ray is up
-// to sqrt(r^2 + 19u(|oc|^2 + r^2)).  A child box is therefore grown, per ray,
-// by  pad = S * m,  m = L1 distance from the ray origin to the box's farthest
-// corner (>= |oc| + r for every sphere inside), S = 1.25e-3 > sqrt(19u) =
-// 1.064e-3; the slack also covers the rounding of the slab arithmetic and of
-// the computed t (a few u relative).  A box is skipped only when the ray misses
-// the grown box, when the grown box lies entirely before t = 0.001, or when it
-// starts beyond the closest hit so far.
+// to sqrt(r^2 + 19u(|oc|^2 + r^2)) <= r + S0*(|oc| + r), S0 = sqrt(19u) =
+// 1.064e-3.  Boxes are therefore grown by  pad = S*D,  S = 1.25e-3, where D
+// bounds |oc| + r of every sphere the ray could still accept; the slack S - S0
+// also covers the rounding of the computed t (a few u relative).  Two rules:
+//
+//   PAD_RAY   one pad per ray: D = min(L1 distance from the origin to the
+//             farthest corner of the tree's bounds, 1.003*(best_t*|d| + 2*r_max))
+//             once a hit at best_t is known.  The slab test is six FMAs on
+//             per-ray constants; their cancellation error (u * |coordinate|)
+//             is covered by an extra 2^-22 * (|o|_1 + abs_max) in the pad.
+//             Good when the tree's extent is small against its spheres.
+//   PAD_NODE  one pad per box: D = L1 distance from the origin to that box's
+//             farthest corner.  Costs about twice the arithmetic per box but
+//             stays tight for near boxes in a sparse, wide scene.
+//
+// A box is skipped only when the ray misses the grown box, when the grown box
+// lies entirely before t = 0.001, or when it starts beyond the closest hit.
 //
 // Closest hit = minimum over (t, upload index) lexicographically, which is what
-// the scan's strict "new_t < t" keeps.  Two corner cases of the scan cannot be
-// decided from a pruned search — a sphere whose accepted root is exactly
-// 0.001f (the scan's "t > 0.001" gate then depends on index order) and a NaN
-// root — so they set `redo` and the caller repeats that ray with the scan.
+// the scan's strict "new_t < t" keeps.  Cases a pruned search cannot decide —
+// an accepted root exactly 0.001f (the scan's "t > 0.001" gate then depends on
+// index order), a NaN root, a traversal stack overflow — set `redo`, and the
+// ray is repeated with the scan.
 // ---------------------------------------------------------------------------
 #define RT_PAD_SCALE 1.25e-3f
+#define RT_T_FLOOR 0.000999f
 
-RT_DEV bool box_test(const float* lo, const float* hi, f3 o, f3 inv_d, float best_t, float& tn_out) {
-  float ax = lo[0] - o.x, bx = hi[0] - o.x;
-  float ay = lo[1] - o.y, by = hi[1] - o.y;
-  float az = lo[2] - o.z, bz = hi[2] - o.z;
-  float m = (fmaxf(-ax, bx) + fmaxf(-ay, by)) + fmaxf(-az, bz);
-  float pad = m * RT_PAD_SCALE;
-  float t0x = (ax - pad) * inv_d.x, t1x = (bx + pad) * inv_d.x;
-  float t0y = (ay - pad) * inv_d.y, t1y = (by + pad) * inv_d.y;
-  float t0z = (az - pad) * inv_d.z, t1z = (bz + pad) * inv_d.z;
-  float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
-  float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-  tn_out = tn;
-  return tn <= tf && tf >= 0.000999f && tn <= best_t;
-}
+struct trav_candidate {
+  float best_t;
+  int best_i;
+  bool redo;
+};
 
+// Exact test of one sphere against the running closest hit.
 template <bool COUNTED>
-RT_DEV void leaf_test(const scene_dev& sc, int kpos, f3 o, f3 d, float a, float& best_t, int& best_i, bool& redo,
-                      lane_counters& k) {
+RT_DEV void consider_sphere(float4 s, int upload_index, f3 o, f3 d, float a, trav_candidate& c, lane_counters& k) {
   RT_COUNT(k, sphere_tests, 1);
-  const float4 s = sc.leaf_sph[kpos];
   float h, disc;
   sphere_disc(s.x, s.y, s.z, s.w, o, d, a, h, disc);
   if (disc >= 0.0f) {
     float t = sphere_roots<COUNTED>(h, disc, a, k);
-    if (t != t || t == 0.001f) redo = true;
-    if (t > 0.001f && t <= best_t) {
-      int idx = sc.leaf_idx[kpos];
-      if (t < best_t || idx < best_i || best_i < 0) {
-        best_t = t;
-        best_i = idx;
-      }
+    if (t != t || t == 0.001f) c.redo = true;
+    if (t > 0.001f && (t < c.best_t || (t == c.best_t && upload_index < c.best_i))) {
+      c.best_t = t;
+      c.best_i = upload_index;
     }
   }
 }
 
-// stack_ref / stack_tn: this lane's column of the wave's LDS stack,
-// element e at [e * 64].
-template <bool COUNTED>
-RT_DEV void hit_bvh(const scene_dev& sc, f3 o, f3 d, int* stack_ref, float* stack_tn, float& t_out, int& i_out,
-                    lane_counters& k) {
+// Per-ray constants of the PAD_RAY slab test: t_lo = lo*inv_d + k_lo, t_hi = hi*inv_d + k_hi.
+struct slab_consts {
+  f3 inv_d, k_lo, k_hi;
+};
+
+RT_DEV float slab_dir(float v) { return fabsf(v) < 1e-20f ? copysignf(1e-20f, v) : v; }
+
+RT_DEV float far_corner_l1(const float* lo, const float* hi, f3 o) {
+  return (fmaxf(o.x - lo[0], hi[0] - o.x) + fmaxf(o.y - lo[1], hi[1] - o.y)) + fmaxf(o.z - lo[2], hi[2] - o.z);
+}
+
+RT_DEV void make_slab_consts(const scene_dev& sc, f3 o, f3 inv_d, float a, const trav_candidate& c, slab_consts& s) {
+  float D = far_corner_l1(sc.root_lo, sc.root_hi, o);
+  if (c.best_i >= 0) D = fminf(D, 1.003f * (c.best_t * sqrtf(a) + 2.0f * sc.r_max));
+  const float pad = RT_PAD_SCALE * D + 2.384186e-7f * ((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z) + sc.abs_max);
+  s.inv_d = inv_d;
+  s.k_lo = mk3(-(o.x + pad) * inv_d.x, -(o.y + pad) * inv_d.y, -(o.z + pad) * inv_d.z);
+  s.k_hi = mk3(-(o.x - pad) * inv_d.x, -(o.y - pad) * inv_d.y, -(o.z - pad) * inv_d.z);
+}
+
+// Entry / exit parameters of the grown box of child `c` of a node.
+template <bool PAD_RAY>
+RT_DEV void child_interval(const float4& lox, const float4& loy, const float4& loz, const float4& hix, const float4& hiy,
+                           const float4& hiz, int c, f3 o, const slab_consts& s, float& tn, float& tf) {
+  const float lx = c == 0 ? lox.x : c == 1 ? lox.y : c == 2 ? lox.z : lox.w;
+  const float ly = c == 0 ? loy.x : c == 1 ? loy.y : c == 2 ? loy.z : loy.w;
+  const float lz = c == 0 ? loz.x : c == 1 ? loz.y : c == 2 ? loz.z : loz.w;
+  const float hx = c == 0 ? hix.x : c == 1 ? hix.y : c == 2 ? hix.z : hix.w;
+  const float hy = c == 0 ? hiy.x : c == 1 ? hiy.y : c == 2 ? hiy.z : hiy.w;
+  const float hz = c == 0 ? hiz.x : c == 1 ? hiz.y : c == 2 ? hiz.z : hiz.w;
+  float t0x, t1x, t0y, t1y, t0z, t1z;
+  if (PAD_RAY) {
+    t0x = __builtin_fmaf(lx, s.inv_d.x, s.k_lo.x); t1x = __builtin_fmaf(hx, s.inv_d.x, s.k_hi.x);
+    t0y = __builtin_fmaf(ly, s.inv_d.y, s.k_lo.y); t1y = __builtin_fmaf(hy, s.inv_d.y, s.k_hi.y);
+    t0z = __builtin_fmaf(lz, s.inv_d.z, s.k_lo.z); t1z = __builtin_fmaf(hz, s.inv_d.z, s.k_hi.z);
+  } else {
+    const float ax = lx - o.x, bx = hx - o.x, ay = ly - o.y, by = hy - o.y, az = lz - o.z, bz = hz - o.z;
+    const float pad = RT_PAD_SCALE * ((fmaxf(-ax, bx) + fmaxf(-ay, by)) + fmaxf(-az, bz));
+    t0x = (ax - pad) * s.inv_d.x; t1x = (bx + pad) * s.inv_d.x;
+    t0y = (ay - pad) * s.inv_d.y; t1y = (by + pad) * s.inv_d.y;
+    t0z = (az - pad) * s.inv_d.z; t1z = (bz + pad) * s.inv_d.z;
+  }
+  tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+  tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+}
+
+// Traversal stack entry.  PACKED (trees of at most 4096 nodes): one word, the
+// entry parameter truncated to 20 bits above the 12-bit node index, so that
+// entries order by distance as unsigned integers.  Otherwise two words.
+template <bool PACKED>
+struct trav_stack;
+
+template <>
+struct trav_stack<true> {
+  uint32_t* col;  // this lane's column: element e at col[e * 64]
+  RT_DEV static uint32_t key(float tn, int ref) { return (__float_as_uint(fmaxf(tn, 0.0f)) & 0xFFFFF000u) | (uint32_t)ref; }
+  RT_DEV static float key_tn(uint32_t k) { return __uint_as_float(k & 0xFFFFF000u); }
+  RT_DEV static int key_ref(uint32_t k) { return (int)(k & 0xFFFu); }
+};
+
+template <>
+struct trav_stack<false> {
+  uint32_t* col;  // refs at col[e * 128], entry parameters at col[e * 128 + 64]
+};
+
+// Memory views the traversal reads: the same arrays either in HBM or staged in LDS.
+struct tree_view {
+  const bvh4_node* nodes;
+  const float4* leaf_sph;
+  const int32_t* leaf_idx;
+};
+
+template <bool PAD_RAY, bool PACKED, int STACK, bool COUNTED>
+RT_DEV void hit_bvh4(const scene_dev& sc, const tree_view& tv, f3 o, f3 d, trav_stack<PACKED> stk, float& t_out,
+                     int& i_out, lane_counters& k) {
   const float a = dot3(d, d);
   if (!(a > 0.0f) || !(a < __builtin_inff())) {  // zero, NaN or overflowing direction: the scan decides
     hit_linear<COUNTED>(sc, o, d, t_out, i_out, k);
     return;
   }
-  const f3 inv_d = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-  float best_t = __builtin_inff();
-  int best_i = -1;
-  bool redo = false;
-  int sp = 0;
-  int cur = sc.root;
-  if (cur < 0) {  // a single sphere
-    leaf_test<COUNTED>(sc, ~cur, o, d, a, best_t, best_i, redo, k);
-  } else {
-    while (true) {
-      const bvh_node* nd = sc.nodes + cur;
-      const float4 q0 = reinterpret_cast<const float4*>(nd)[0];
-      const float4 q1 = reinterpret_cast<const float4*>(nd)[1];
-      const float4 q2 = reinterpret_cast<const float4*>(nd)[2];
-      const int2 ch = reinterpret_cast<const int2*>(nd)[6];
-      const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q0.w, q1.x, q1.y};
-      const float lo1[3] = {q1.z, q1.w, q2.x}, hi1[3] = {q2.y, q2.z, q2.w};
-      float tn0 = 0.0f, tn1 = 0.0f;
-      bool go0 = false, go1 = false;
-      // A leaf child is one sphere: its exact test costs no more than its box.
-      if (ch.x < 0) {
-        leaf_test<COUNTED>(sc, ~ch.x, o, d, a, best_t, best_i, redo, k);
-      } else {
-        RT_COUNT(k, node_tests, 1);
-        go0 = box_test(lo0, hi0, o, inv_d, best_t, tn0);
-      }
-      if (ch.y < 0) {
-        leaf_test<COUNTED>(sc, ~ch.y, o, d, a, best_t, best_i, redo, k);
-      } else {
-        RT_COUNT(k, node_tests, 1);
-        go1 = box_test(lo1, hi1, o, inv_d, best_t, tn1);
-      }
-      // a leaf hit found just now may already rule out the sibling subtree
-      go0 = go0 && tn0 <= best_t;
-      go1 = go1 && tn1 <= best_t;
-      if (go0 && go1) {
-        const bool first0 = tn0 <= tn1;
-        const int far = first0 ? ch.y : ch.x;
-        const float far_tn = first0 ? tn1 : tn0;
-        stack_ref[sp * 64] = far;
-        stack_tn[sp * 64] = far_tn;
-        sp++;
-        cur = first0 ? ch.x : ch.y;
-        continue;
-      }
-      if (go0) {
-        cur = ch.x;
-        continue;
-      }
-      if (go1) {
-        cur = ch.y;
-        continue;
-      }
-      bool found = false;
-      while (sp > 0) {
-        sp--;
-        const float tn = stack_tn[sp * 64];
-        if (tn <= best_t) {
-          cur = stack_ref[sp * 64];
-          found = true;
-          break;
+  trav_candidate c;
+  c.best_t = __builtin_inff();
+  c.best_i = -1;
+  c.redo = false;
+
+  // spheres kept out of the tree: exact tests, wave-uniform index
+  for (int j = 0; j < sc.n_big; j++) consider_sphere<COUNTED>(sc.big_sph[j], sc.big_idx[j], o, d, a, c, k);
+
+  if (sc.n_leaf > 0) {
+    // Box tests only: a direction component closer to zero than 1e-20 is
+    // treated as +-1e-20, which keeps every slab parameter finite (a ray
+    // that flat is inside or outside the slab for its whole length either way).
+    const f3 inv_d = mk3(__builtin_amdgcn_rcpf(slab_dir(d.x)), __builtin_amdgcn_rcpf(slab_dir(d.y)),
+                         __builtin_amdgcn_rcpf(slab_dir(d.z)));
+    slab_consts sl;
+    sl.inv_d = inv_d;
+    if (PAD_RAY) make_slab_consts(sc, o, inv_d, a, c, sl);
+    int cur = sc.root;
+    if (cur < 0) {  // a single sphere in the tree
+      consider_sphere<COUNTED>(tv.leaf_sph[~cur], tv.leaf_idx[~cur], o, d, a, c, k);
+    } else {
+      int sp = 0;
+      while (true) {
+        const bvh4_node* nd = tv.nodes + cur;
+        const float4 lox = reinterpret_cast<const float4*>(nd)[0];
+        const float4 loy = reinterpret_cast<const float4*>(nd)[1];
+        const float4 loz = reinterpret_cast<const float4*>(nd)[2];
+        const float4 hix = reinterpret_cast<const float4*>(nd)[3];
+        const float4 hiy = reinterpret_cast<const float4*>(nd)[4];
+        const float4 hiz = reinterpret_cast<const float4*>(nd)[5];
+        const int4 ref = reinterpret_cast<const int4*>(nd)[6];
+        const int refs[4] = {ref.x, ref.y, ref.z, ref.w};
+        float tn[4], tf[4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++) child_interval<PAD_RAY>(lox, loy, loz, hix, hiy, hiz, ch, o, sl, tn[ch], tf[ch]);
+        // leaves first: an exact hit shortens the ray for the boxes below
+        unsigned leaf_mask = 0;
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++) {
+          const bool valid = refs[ch] != RT_REF_EMPTY;
+          RT_COUNT(k, node_tests, valid ? 1u : 0u);
+          if (valid && refs[ch] < 0 && tn[ch] <= tf[ch] && tf[ch] >= RT_T_FLOOR && tn[ch] <= c.best_t) leaf_mask |= 1u << ch;
+        }
+        while (leaf_mask) {
+          const int ch = __builtin_ctz(leaf_mask);
+          leaf_mask &= leaf_mask - 1;
+          const int r = ch == 0 ? refs[0] : ch == 1 ? refs[1] : ch == 2 ? refs[2] : refs[3];
+          const int pos = ~r;
+          consider_sphere<COUNTED>(tv.leaf_sph[pos], tv.leaf_idx[pos], o, d, a, c, k);
+        }
+        if (PACKED) {
+          uint32_t key[4];
+#pragma unroll
+          for (int ch = 0; ch < 4; ch++) {
+            const bool go = refs[ch] >= 0 && tn[ch] <= tf[ch] && tf[ch] >= RT_T_FLOOR && tn[ch] <= c.best_t;
+            key[ch] = go ? trav_stack<true>::key(tn[ch], refs[ch]) : 0xFFFFFFFFu;
+          }
+          // sort the four keys ascending (invalid = all ones sinks to the end)
+#define RT_CE(i, j)                               \
+  do {                                            \
+    const uint32_t lo_ = min(key[i], key[j]);     \
+    key[j] = max(key[i], key[j]);                 \
+    key[i] = lo_;                                 \
+  } while (0)
+          RT_CE(0, 1); RT_CE(2, 3); RT_CE(0, 2); RT_CE(1, 3); RT_CE(1, 2);
+#undef RT_CE
+          // farthest first, so the nearest is popped first
+#pragma unroll
+          for (int e = 3; e >= 1; e--) {
+            if (key[e] != 0xFFFFFFFFu) {
+              if (sp < STACK) stk.col[sp * 64] = key[e];
+              else c.redo = true;
+              sp += sp < STACK ? 1 : 0;
+            }
+          }
+          if (key[0] != 0xFFFFFFFFu) {
+            cur = trav_stack<true>::key_ref(key[0]);
+            continue;
+          }
+          bool found = false;
+          while (sp > 0) {
+            sp--;
+            const uint32_t e = stk.col[sp * 64];
+            if (trav_stack<true>::key_tn(e) <= c.best_t) {
+              cur = trav_stack<true>::key_ref(e);
+              found = true;
+              break;
+            }
+          }
+          if (!found) break;
+        } else {
+          // nearest child continues, the others are pushed with their entry parameter
+          int near = -1;
+          float near_tn = __builtin_inff();
+          bool go[4];
+#pragma unroll
+          for (int ch = 0; ch < 4; ch++) {
+            go[ch] = refs[ch] >= 0 && tn[ch] <= tf[ch] && tf[ch] >= RT_T_FLOOR && tn[ch] <= c.best_t;
+            if (go[ch] && (near < 0 || tn[ch] < near_tn)) {
+              near = ch;
+              near_tn = tn[ch];
+            }
+          }
+#pragma unroll
+          for (int ch = 0; ch < 4; ch++) {
+            if (go[ch] && ch != near) {
+              if (sp < STACK) {
+                stk.col[sp * 128] = (uint32_t)refs[ch];
+                stk.col[sp * 128 + 64] = __float_as_uint(tn[ch]);
+                sp++;
+              } else {
+                c.redo = true;
+              }
+            }
+          }
+          if (near >= 0) {
+            cur = near == 0 ? refs[0] : near == 1 ? refs[1] : near == 2 ? refs[2] : refs[3];
+            continue;
+          }
+          bool found = false;
+          while (sp > 0) {
+            sp--;
+            if (__uint_as_float(stk.col[sp * 128 + 64]) <= c.best_t) {
+              cur = (int)stk.col[sp * 128];
+              found = true;
+              break;
+            }
+          }
+          if (!found) break;
         }
       }
-      if (!found) break;
     }
   }
-  if (redo) {
+  if (c.redo) {
     hit_linear<COUNTED>(sc, o, d, t_out, i_out, k);
     return;
   }
-  t_out = best_i >= 0 ? best_t : -1.0f;
-  i_out = best_i;
+  t_out = c.best_i >= 0 ? c.best_t : -1.0f;
+  i_out = c.best_i;
 }
