@@ -111,7 +111,11 @@ struct rt_ctx {
   int samples_lo = 0, samples_hi = 0, samples_override = -1;
 
   dev_buf<uint32_t> seed_tex;
-  dev_buf<unsigned int> queue;
+  dev_buf<unsigned long long> queue;  // work-queue head of the running launch
+  // two-pass rendering: per-pixel carry of the probe pass and the sorted pixel order
+  dev_buf<float> carry_colour;
+  dev_buf<uint32_t> carry_rng, carry_key, carry_idx, order_key, order_idx;
+  dev_buf<unsigned char> sort_temp;
   int n_cu = 0;
   dev_buf<unsigned long long> counters;
   dev_buf<float> out_linear;
@@ -280,6 +284,28 @@ const char* search_name(int search, bool render) {
   }
 }
 
+// Ready lanes a wave waits for before it interrupts traversal for the path
+// phase (RT_PHASE_VOTE in the environment overrides the default, for tuning).
+int phase_vote() {
+  static int v = [] {
+    const char* e = getenv("RT_PHASE_VOTE");
+    int x = e ? atoi(e) : RT_PHASE_VOTE;
+    return x < 1 ? 1 : (x > 64 ? 64 : x);
+  }();
+  return v;
+}
+
+// Samples per pixel of the cost-probe pass, and the switch for two-pass
+// rendering (RT_TWO_PASS=0 in the environment turns it off, for comparison).
+constexpr int kProbeSamples = 16;
+bool two_pass_enabled() {
+  static bool v = [] {
+    const char* e = getenv("RT_TWO_PASS");
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
+
 int check_ctx(rt_ctx* c) {
   if (!c) return fail(RT_ERR_INVALID, "null context");
   HIP_TRY(hipSetDevice(c->device));
@@ -340,11 +366,18 @@ hipError_t launch_render(const rt_ctx* c, const rt_params* p, bool counted, hipS
 template <int SEARCH, bool COUNTED>
 hipError_t launch_trace_one(const rt_ctx* c, hipStream_t st, const trace_args& a) {
   using T = search_traits<SEARCH>;
-  const unsigned blocks = (unsigned)((a.n + T::threads - 1) / T::threads);
   const size_t lds = search_lds_bytes<SEARCH>(c->n_nodes, c->n_leaf);
   hipError_t e = allow_lds(rt_trace_kernel<SEARCH, COUNTED>, lds);
   if (e != hipSuccess) return e;
-  rt_trace_kernel<SEARCH, COUNTED><<<blocks, T::threads, lds, st>>>(a);
+  int per_cu = 0;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_trace_kernel<SEARCH, COUNTED>, T::threads, lds);
+  if (e != hipSuccess) return e;
+  if (per_cu < 1) per_cu = 1;
+  long long blocks = (long long)per_cu * c->n_cu;
+  const long long needed = (long long)((a.n + T::threads - 1) / T::threads);
+  if (blocks > needed) blocks = needed;
+  if (blocks < 1) blocks = 1;
+  rt_trace_kernel<SEARCH, COUNTED><<<dim3((unsigned)blocks), T::threads, lds, st>>>(a);
   return hipGetLastError();
 }
 
@@ -387,7 +420,8 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   a.seed_tex = nullptr;
   a.counters = nullptr;
   HIP_TRY(c->queue.resize(1));
-  a.queue = c->queue.p;
+  a.queue = reinterpret_cast<unsigned int*>(c->queue.p);
+  a.vote = phase_vote();
   if (p->rng_mode == RT_RNG_XORSHIFT_REF && p->seed_tex) {
     HIP_TRY(c->seed_tex.resize(n_px));
     HIP_TRY(hipMemcpyAsync(c->seed_tex.p, p->seed_tex, n_px * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
@@ -400,15 +434,63 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   }
   const int tw = p->tile_x1 - p->tile_x0, th = p->tile_y1 - p->tile_y0;
   if (tw == 0 || th == 0 || p->sample_end == p->sample_begin) return RT_OK;
-  HIP_TRY(hipMemsetAsync(c->queue.p, 0, sizeof(unsigned int), c->stream));
+  auto launch = [&](const render_args& ra, const rt_params* rp) -> hipError_t {
+    hipError_t qe = hipMemsetAsync(c->queue.p, 0, sizeof(unsigned long long), c->stream);
+    if (qe != hipSuccess) return qe;
+    switch (c->search) {
+      case SEARCH_TREE_LDS_RAY: return launch_render<SEARCH_TREE_LDS_RAY>(c, rp, counted, c->stream, ra);
+      case SEARCH_TREE_LDS_NODE: return launch_render<SEARCH_TREE_LDS_NODE>(c, rp, counted, c->stream, ra);
+      case SEARCH_TREE_GLB_RAY: return launch_render<SEARCH_TREE_GLB_RAY>(c, rp, counted, c->stream, ra);
+      case SEARCH_TREE_GLB_NODE: return launch_render<SEARCH_TREE_GLB_NODE>(c, rp, counted, c->stream, ra);
+      default: return launch_render<SEARCH_LINEAR>(c, rp, counted, c->stream, ra);
+    }
+  };
+  a.pass = 0;
+  a.order = nullptr;
+  a.carry_colour = nullptr;
+  a.carry_rng = a.carry_key = a.carry_idx = nullptr;
+  // A pixel is the unit of work (its sum must be formed in sample order), so
+  // the launch ends with the lanes that drew the most expensive pixels last.
+  // With enough samples a short probe pass measures every pixel's cost, the
+  // pixels are sorted most-expensive-first, and the main pass takes them in
+  // that order: the tail then consists of the cheapest pixels.
+  const size_t n_rect = (size_t)tw * (size_t)th;
+  const int n_samples = p->sample_end - p->sample_begin;
+  const bool two_pass = two_pass_enabled() && n_samples >= 4 * kProbeSamples && n_rect >= 16384;
   HIP_TRY(hipEventRecord(c->ev_k0, c->stream));
   hipError_t e;
-  switch (c->search) {
-    case SEARCH_TREE_LDS_RAY: e = launch_render<SEARCH_TREE_LDS_RAY>(c, p, counted, c->stream, a); break;
-    case SEARCH_TREE_LDS_NODE: e = launch_render<SEARCH_TREE_LDS_NODE>(c, p, counted, c->stream, a); break;
-    case SEARCH_TREE_GLB_RAY: e = launch_render<SEARCH_TREE_GLB_RAY>(c, p, counted, c->stream, a); break;
-    case SEARCH_TREE_GLB_NODE: e = launch_render<SEARCH_TREE_GLB_NODE>(c, p, counted, c->stream, a); break;
-    default: e = launch_render<SEARCH_LINEAR>(c, p, counted, c->stream, a); break;
+  if (!two_pass) {
+    e = launch(a, p);
+  } else {
+    HIP_TRY(c->carry_colour.resize(3 * n_rect));
+    HIP_TRY(c->carry_rng.resize(n_rect));
+    HIP_TRY(c->carry_key.resize(n_rect));
+    HIP_TRY(c->carry_idx.resize(n_rect));
+    HIP_TRY(c->order_key.resize(n_rect));
+    HIP_TRY(c->order_idx.resize(n_rect));
+    size_t temp_bytes = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, c->carry_key.p, c->order_key.p, c->carry_idx.p, c->order_idx.p,
+                                      n_rect, 0, 12, c->stream));
+    HIP_TRY(c->sort_temp.resize(temp_bytes > 0 ? temp_bytes : 1));
+    render_args probe = a;
+    probe.pass = 1;
+    probe.p.sample_end = p->sample_begin + kProbeSamples;
+    probe.carry_colour = c->carry_colour.p;
+    probe.carry_rng = c->carry_rng.p;
+    probe.carry_key = c->carry_key.p;
+    probe.carry_idx = c->carry_idx.p;
+    e = launch(probe, p);
+    if (e == hipSuccess)
+      e = rocprim::radix_sort_pairs(c->sort_temp.p, temp_bytes, c->carry_key.p, c->order_key.p, c->carry_idx.p,
+                                    c->order_idx.p, n_rect, 0, 12, c->stream);
+    if (e == hipSuccess) {
+      render_args mainp = probe;
+      mainp.pass = 2;
+      mainp.p.sample_begin = p->sample_begin + kProbeSamples;
+      mainp.p.sample_end = p->sample_end;
+      mainp.order = c->order_idx.p;
+      e = launch(mainp, p);
+    }
   }
   if (e != hipSuccess) return fail(RT_ERR_DEVICE, "render launch: %s", hipGetErrorString(e));
   c->last_kernel = search_name(c->search, true);
@@ -464,7 +546,9 @@ void rt_destroy(rt_ctx* c) {
   c->sph.release(); c->inv_r.release(); c->sph_mat.release(); c->mat_type.release(); c->mat_a.release();
   c->big_sph.release(); c->big_idx.release(); c->tree_sph.release(); c->tree_r.release(); c->tree_orig.release();
   c->nodes.release(); c->leaf_sph.release(); c->leaf_r.release(); c->leaf_idx.release();
-  c->accum_own.release(); c->seed_tex.release(); c->queue.release(); c->counters.release(); c->out_linear.release(); c->out_rgb8.release();
+  c->accum_own.release(); c->seed_tex.release(); c->queue.release(); c->counters.release();
+  c->carry_colour.release(); c->carry_rng.release(); c->carry_key.release(); c->carry_idx.release();
+  c->order_key.release(); c->order_idx.release(); c->sort_temp.release(); c->out_linear.release(); c->out_rgb8.release();
   if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
   if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
   if (c->ev_b0) (void)hipEventDestroy(c->ev_b0);
@@ -661,11 +745,15 @@ int rt_trace_batch_device(rt_ctx* c, const float* o_xyz, const float* d_xyz, siz
   a.t = t;
   a.nrm = nrm;
   a.counters = nullptr;
+  HIP_TRY(c->queue.resize(1));
+  a.queue = c->queue.p;
+  a.vote = phase_vote();
   if (counted) {
     HIP_TRY(c->counters.resize(sizeof(rt_counters) / sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(rt_counters), c->stream));
     a.counters = c->counters.p;
   }
+  HIP_TRY(hipMemsetAsync(c->queue.p, 0, sizeof(unsigned long long), c->stream));
   HIP_TRY(hipEventRecord(c->ev_k0, c->stream));
   hipError_t e;
   switch (c->search) {

@@ -47,15 +47,30 @@ struct render_args {
   const uint32_t* seed_tex;    // device copy of p.seed_tex, or null
   unsigned long long* counters;  // sizeof(rt_counters)/8 words, or null
   unsigned int* queue;         // head of the pixel queue, zero at launch
+  int vote;                    // ready lanes needed before a wave leaves traversal for the path phase
+  // Two-pass rendering (pixel queue ordered by measured cost):
+  //   pass 0  everything in one launch, queue in tile order
+  //   pass 1  probe: the first few samples of every pixel in tile order; leaves the pixel's
+  //           running sum, RNG state and segment count in the carry arrays, not in accum
+  //   pass 2  main: the remaining samples, pixels taken from `order` (most expensive first),
+  //           each continuing from its carried sum and RNG state
+  int pass;
+  const uint32_t* order;       // pass 2: rect-pixel indices, heaviest first
+  float* carry_colour;         // 3 floats per rect pixel
+  uint32_t* carry_rng;
+  uint32_t* carry_key;         // pass 1 writes the sort key (small = expensive) ...
+  uint32_t* carry_idx;         // ... and the rect-pixel index it belongs to
 };
 
 template <bool COUNTED>
 RT_DEV void flush_counters(unsigned long long* g, const lane_counters& k) {
   if (!COUNTED || g == nullptr) return;
-  const uint32_t v[14] = {k.paths,      k.segments, k.sphere_tests, k.roots,  k.node_tests, k.hits,       k.sky,
-                          k.lambertian, k.metallic, k.dialectric,   k.perlin, k.unit_tries, k.disk_tries, k.limit_hits};
+  const uint32_t v[18] = {k.paths,           k.segments,        k.sphere_tests,     k.roots,           k.node_tests,
+                          k.hits,            k.sky,             k.lambertian,       k.metallic,        k.dialectric,
+                          k.perlin,          k.unit_tries,      k.disk_tries,       k.limit_hits,      k.trav_wave_steps,
+                          k.trav_lane_steps, k.path_wave_phases, k.path_lane_phases};
 #pragma unroll
-  for (int i = 0; i < 14; i++) {
+  for (int i = 0; i < 18; i++) {
     // sum over the wave first: one atomic per wave and counter
     unsigned long long s = v[i];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
@@ -100,28 +115,49 @@ RT_DEV void search_setup(const scene_dev& sc, tree_view& tv, uint32_t*& stack_co
   stack_col = reinterpret_cast<uint32_t*>(base) + wave * T::stack_words + lane;
 }
 
+// The search object of a kernel: the stepwise tree search, or for the linear
+// scan an object whose begin() does the whole scan.
 template <int SEARCH, bool COUNTED>
-RT_DEV void closest_hit(const scene_dev& sc, const tree_view& tv, uint32_t* stack_col, f3 o, f3 d, float& t, int& idx,
-                        lane_counters& k) {
+struct searcher {
   using T = search_traits<SEARCH>;
-  if (T::tree) {
+  tree_search<T::pad_ray, T::lds, T::stack, COUNTED> ts;
+  RT_DEV bool begin(const scene_dev& sc, const tree_view& tv, f3 o, f3 d, lane_counters& k) {
+    if (T::tree) return ts.begin(sc, tv, o, d, k);
+    ts.o = o;
+    ts.d = d;
+    ts.c.redo = true;  // finish() runs the scan
+    return false;
+  }
+  RT_DEV bool step(const tree_view& tv, uint32_t* stack_col, lane_counters& k) {
     trav_stack<T::lds> stk;
     stk.col = stack_col;
-    hit_bvh4<T::pad_ray, T::lds, T::stack, COUNTED>(sc, tv, o, d, stk, t, idx, k);
-  } else {
-    hit_linear<COUNTED>(sc, o, d, t, idx, k);
+    return ts.step(tv, stk, k);
   }
-}
+  RT_DEV void finish(const scene_dev& sc, float& t, int& idx, lane_counters& k) { ts.finish(sc, t, idx, k); }
+};
 
-// Persistent lanes.  The launch holds as many workgroups as the chip keeps
-// resident; every lane pulls pixels from one global queue (the compiler folds
-// the per-lane atomicAdd into one atomic per wave, ranked by ballot / mbcnt)
-// and keeps pulling until the queue is dry, so no wave waits for the slowest
-// pixel of a fixed tile.  Queue order: 8x8-pixel tiles, a tile's 64 pixels
+// Lanes of a wave that are ready for their path phase wait until this many of
+// them are (or until no lane is traversing); until then the wave keeps taking
+// traversal steps for the others.
+#define RT_PHASE_VOTE 24
+
+// Persistent lanes with phase voting.
+//
+// The launch holds as many workgroups as the chip keeps resident.  Every lane
+// pulls pixels from one global queue (the compiler folds the per-lane atomicAdd
+// into one atomic per wave, ranked by ballot / mbcnt) and keeps pulling until
+// the queue is dry.  Queue order: 8x8-pixel tiles, a tile's 64 pixels
 // consecutive, so a wave starts on one coherent tile.  A lane owns its pixel
-// for the whole sample range: it regenerates a camera ray the moment a path
-// ends and forms the pixel's sum in sample order in registers — no atomics on
-// the image, and bit-identical to a sequential evaluation.
+// for the whole sample range and forms the pixel's sum in sample order in
+// registers — no atomics on the image, bit-identical to a sequential evaluation.
+//
+// A lane is either traversing the tree or ready for its path phase (shade the
+// hit or the sky, close the sample, fetch a pixel, start a camera ray, set up
+// the next segment).  Each iteration the wave takes ONE of the two actions,
+// chosen by ballot: a traversal step for the traversing lanes, or the path
+// phase for the ready ones.  Rays that finish their traversal early therefore
+// do not hold the wave until the slowest ray of the segment is done; they wait
+// only until enough lanes are ready to make the path phase worth issuing.
 template <int SEARCH, int RNG, bool COUNTED>
 __global__ __launch_bounds__(search_traits<SEARCH>::threads) void rt_render_kernel(const render_args A) {
   const rt_params& P = A.p;
@@ -132,7 +168,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads) void rt_render_kern
 
   const int tw = P.tile_x1 - P.tile_x0, th = P.tile_y1 - P.tile_y0;
   const int tiles_x = (tw + 7) >> 3, tiles_y = (th + 7) >> 3;
-  const uint32_t total_items = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
+  const uint32_t total_items = A.pass == 2 ? (uint32_t)tw * (uint32_t)th : (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
 
   lane_counters k = {};
   const f3 delta_u = mk3(P.delta_u[0], P.delta_u[1], P.delta_u[2]);
@@ -142,38 +178,137 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads) void rt_render_kern
   const f3 ddu = mk3(P.defocus_disk_u[0], P.defocus_disk_u[1], P.defocus_disk_u[2]);
   const f3 ddv = mk3(P.defocus_disk_v[0], P.defocus_disk_v[1], P.defocus_disk_v[2]);
 
-  bool have = false;       // this lane owns a pixel
+  searcher<SEARCH, COUNTED> srch;
+  bool have = false;        // this lane owns a pixel
+  bool alive = false;       // a path of that pixel is in flight
+  bool pending = false;     // a finished search waits to be shaded
+  bool in_trav = false;     // the search needs more steps
   bool exhausted = P.sample_end <= P.sample_begin;
   int x = 0, y = 0, s = 0;
-  uint32_t pixel = 0, rng = 0, count = 0;
-  bool alive = false;
+  uint32_t pixel = 0, rect_pixel = 0, rng = 0, count = 0, pixel_segments = 0;
   f3 colour = mk3(0.0f, 0.0f, 0.0f);
-  f3 o = colour, d = colour, alb = colour;
+  f3 alb = colour;
 
-  while (!exhausted) {
-    if (!have) {  // pull the next pixel
-      const uint32_t item = atomicAdd(A.queue, 1u);
-      if (item >= total_items) {
-        exhausted = true;
-      } else {
-        const uint32_t tile = item >> 6, within = item & 63u;
-        x = P.tile_x0 + (int)(tile % (uint32_t)tiles_x) * 8 + (int)(within & 7u);
-        y = P.tile_y0 + (int)(tile / (uint32_t)tiles_x) * 8 + (int)(within >> 3);
-        if (x < P.tile_x1 && y < P.tile_y1) {
-          have = true;
-          pixel = (uint32_t)y * (uint32_t)P.width + (uint32_t)x;
-          s = P.sample_begin;
-          alive = false;
-          colour = mk3(0.0f, 0.0f, 0.0f);
-          if (RNG == RT_RNG_XORSHIFT_REF) {
-            const uint32_t seed = A.seed_tex ? A.seed_tex[pixel] : 0u;  // fs:105-106
-            rng = seed ^ cantor_pair((uint32_t)x, (uint32_t)y);         // fs:107
+  // The pixel's sample range is over: pass 0 / 2 add its sum to the image, the
+  // probe pass parks it (with the RNG state and a cost key) for pass 2.
+  auto close_pixel = [&]() {
+    if (A.pass == 1) {
+      float* dst = A.carry_colour + 3 * (size_t)rect_pixel;
+      dst[0] = colour.x;
+      dst[1] = colour.y;
+      dst[2] = colour.z;
+      A.carry_rng[rect_pixel] = rng;
+      A.carry_key[rect_pixel] = 4095u - min(pixel_segments, 4095u);
+      A.carry_idx[rect_pixel] = rect_pixel;
+    } else {
+      float* dst = A.accum + 3 * (size_t)pixel;
+      dst[0] += colour.x;
+      dst[1] += colour.y;
+      dst[2] += colour.z;
+    }
+    have = false;
+  };
+
+  while (true) {
+    const unsigned long long m_trav = __ballot(in_trav);
+    const unsigned long long m_ready = __ballot(!in_trav && !exhausted);
+    if ((m_trav | m_ready) == 0ull) break;
+    const bool path_phase = m_trav == 0ull || __popcll(m_ready) >= A.vote;
+    if (!path_phase) {
+      RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
+      RT_COUNT(k, trav_lane_steps, in_trav ? 1u : 0u);
+      if (in_trav) in_trav = srch.step(tv, stack_col, k);  // `pending` (set at begin) marks the result as unread
+      continue;
+    }
+    RT_COUNT(k, path_wave_phases, (threadIdx.x & 63) == 0 ? 1u : 0u);
+    if (in_trav || exhausted) continue;  // only ready lanes take the path phase
+    RT_COUNT(k, path_lane_phases, 1);
+
+    bool start_segment = false;
+    if (pending) {  // the search for the current segment is over: bounce(), fs:207-219
+      pending = false;
+      float t;
+      int idx;
+      srch.finish(sc, t, idx, k);
+      const f3 o = srch.ts.o;
+      f3 d = srch.ts.d;
+      bool cont;
+      f3 next_o = o;
+      if (t > 0.001f) {  // fs:186-196
+        RT_COUNT(k, hits, 1);
+        const float4 sp = sc.sph[idx];
+        hit_rec h;
+        h.point = o + d * t;
+        h.normal = sc.inv_r[idx] * (h.point - mk3(sp.x, sp.y, sp.z));
+        h.interior = false;
+        if (dot3(h.normal, d) >= 0.0f) {
+          h.normal = -h.normal;
+          h.interior = true;
+        }
+        h.mat = sc.sph_mat[idx];
+        const float4 ma = sc.mat_a[h.mat];
+        const int type = sc.mat_type[h.mat];
+        next_o = h.point;  // fs:211-212
+        count = count + 1u;
+        cont = shade_hit<RNG, COUNTED>(h, type, ma.w, mk3(ma.x, ma.y, ma.z), d, alb, rng, k);
+      } else {  // fs:217-218
+        alb = sky_radiance(d, alb);
+        cont = false;
+        RT_COUNT(k, sky, 1);
+      }
+      if (cont && count >= P.bounce_limit) {  // the next bounce() would stop here, fs:203-205
+        alb = mk3(0.0f, 0.0f, 0.0f);
+        cont = false;
+        RT_COUNT(k, limit_hits, 1);
+      }
+      if (cont) {
+        srch.ts.o = next_o;
+        srch.ts.d = d;
+        start_segment = true;
+      } else {  // fs:132: colour += raycast(...)
+        colour = colour + alb;
+        alive = false;
+        s++;
+        if (s >= P.sample_end) close_pixel();
+      }
+    }
+    if (!start_segment) {
+      if (!have) {  // pull the next pixel
+        const uint32_t item = atomicAdd(A.queue, 1u);
+        if (item >= total_items) {
+          exhausted = true;
+        } else {
+          if (A.pass == 2) {
+            rect_pixel = A.order[item];
+            x = P.tile_x0 + (int)(rect_pixel % (uint32_t)tw);
+            y = P.tile_y0 + (int)(rect_pixel / (uint32_t)tw);
+          } else {
+            const uint32_t tile = item >> 6, within = item & 63u;
+            x = P.tile_x0 + (int)(tile % (uint32_t)tiles_x) * 8 + (int)(within & 7u);
+            y = P.tile_y0 + (int)(tile / (uint32_t)tiles_x) * 8 + (int)(within >> 3);
+            rect_pixel = (uint32_t)(y - P.tile_y0) * (uint32_t)tw + (uint32_t)(x - P.tile_x0);
+          }
+          if (x < P.tile_x1 && y < P.tile_y1) {
+            have = true;
+            pixel = (uint32_t)y * (uint32_t)P.width + (uint32_t)x;
+            s = P.sample_begin;
+            alive = false;
+            pixel_segments = 0;
+            if (A.pass == 2) {  // continue the sum and the RNG stream the probe pass left
+              const float* src = A.carry_colour + 3 * (size_t)rect_pixel;
+              colour = mk3(src[0], src[1], src[2]);
+              rng = A.carry_rng[rect_pixel];
+            } else {
+              colour = mk3(0.0f, 0.0f, 0.0f);
+              if (RNG == RT_RNG_XORSHIFT_REF) {
+                const uint32_t seed = A.seed_tex ? A.seed_tex[pixel] : 0u;  // fs:105-106
+                rng = seed ^ cantor_pair((uint32_t)x, (uint32_t)y);         // fs:107
+              }
+            }
           }
         }
       }
-    }
-    if (have) {
-      if (!alive) {  // fs:117-131: next camera sample of this pixel
+      if (have && !alive) {  // fs:117-131: next camera sample of this pixel
         if (RNG == RT_RNG_COUNTER) rng = counter_key(P.seed, pixel, (uint32_t)s);
         const float jx = rng_float<RNG>(rng) - 0.5f;
         const float jy = rng_float<RNG>(rng) - 0.5f;
@@ -183,58 +318,29 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads) void rt_render_kern
           const f3 rd = random_unit_disk<RNG, COUNTED>(rng, k);
           ro = cam + rd.x * ddu + rd.y * ddv;
         }
-        o = ro;
-        d = frag - ro;
         alb = mk3(1.0f, 1.0f, 1.0f);
         count = 0;
         alive = true;
         RT_COUNT(k, paths, 1);
-      }
-      bool cont;
-      if (count >= P.bounce_limit) {  // fs:203-205
-        alb = mk3(0.0f, 0.0f, 0.0f);
-        cont = false;
-        RT_COUNT(k, limit_hits, 1);
-      } else {
-        RT_COUNT(k, segments, 1);
-        float t;
-        int idx;
-        closest_hit<SEARCH, COUNTED>(sc, tv, stack_col, o, d, t, idx, k);
-        if (t > 0.001f) {  // fs:186-196
-          RT_COUNT(k, hits, 1);
-          const float4 sp = sc.sph[idx];
-          hit_rec h;
-          h.point = o + d * t;
-          h.normal = sc.inv_r[idx] * (h.point - mk3(sp.x, sp.y, sp.z));
-          h.interior = false;
-          if (dot3(h.normal, d) >= 0.0f) {
-            h.normal = -h.normal;
-            h.interior = true;
-          }
-          h.mat = sc.sph_mat[idx];
-          const float4 ma = sc.mat_a[h.mat];
-          const int type = sc.mat_type[h.mat];
-          o = h.point;  // fs:211-212
-          count = count + 1u;
-          cont = shade_hit<RNG, COUNTED>(h, type, ma.w, mk3(ma.x, ma.y, ma.z), d, alb, rng, k);
-        } else {  // fs:217-218
-          alb = sky_radiance(d, alb);
-          cont = false;
-          RT_COUNT(k, sky, 1);
+        if (P.bounce_limit == 0u) {  // fs:203-205 on the first bounce()
+          alb = mk3(0.0f, 0.0f, 0.0f);
+          RT_COUNT(k, limit_hits, 1);
+          colour = colour + alb;
+          alive = false;
+          s++;
+          if (s >= P.sample_end) close_pixel();
+        } else {
+          srch.ts.o = ro;
+          srch.ts.d = frag - ro;
+          start_segment = true;
         }
       }
-      if (!cont) {  // fs:132: colour += raycast(...)
-        colour = colour + alb;
-        alive = false;
-        s++;
-        if (s >= P.sample_end) {  // the pixel is finished: one read-modify-write of its accumulator
-          float* dst = A.accum + 3 * (size_t)pixel;
-          dst[0] += colour.x;
-          dst[1] += colour.y;
-          dst[2] += colour.z;
-          have = false;
-        }
-      }
+    }
+    if (start_segment) {
+      RT_COUNT(k, segments, 1);
+      pixel_segments++;
+      in_trav = srch.begin(sc, tv, srch.ts.o, srch.ts.d, k);
+      pending = true;
     }
   }
   flush_counters<COUNTED>(A.counters, k);
@@ -249,42 +355,72 @@ struct trace_args {
   float* t;
   float* nrm;
   unsigned long long* counters;
+  unsigned long long* queue;  // next ray index, zero at launch
+  int vote;
 };
 
-// hit_any (fs:165-199) for a batch of rays, one ray per lane.
+// hit_any (fs:165-199) for a batch of rays: persistent lanes pull ray indices
+// from a queue, with the same phase voting as the renderer (a lane that has
+// finished its ray fetches the next one while others keep traversing).
 template <int SEARCH, bool COUNTED>
 __global__ __launch_bounds__(search_traits<SEARCH>::threads) void rt_trace_kernel(const trace_args A) {
-  using T = search_traits<SEARCH>;
   const scene_dev& sc = A.sc;
   tree_view tv;
   uint32_t* stack_col;
   search_setup<SEARCH>(sc, tv, stack_col);
   lane_counters k = {};
-  const size_t i = (size_t)blockIdx.x * T::threads + threadIdx.x;
-  if (i < A.n) {
-    const f3 o = mk3(A.o_xyz[3 * i], A.o_xyz[3 * i + 1], A.o_xyz[3 * i + 2]);
-    const f3 d = mk3(A.d_xyz[3 * i], A.d_xyz[3 * i + 1], A.d_xyz[3 * i + 2]);
-    RT_COUNT(k, segments, 1);
-    float t;
-    int idx;
-    closest_hit<SEARCH, COUNTED>(sc, tv, stack_col, o, d, t, idx, k);
-    f3 n = mk3(0.0f, 0.0f, 0.0f);
-    int id = -1;
-    float tt = -1.0f;
-    if (t > 0.001f) {
-      RT_COUNT(k, hits, 1);
-      const float4 sp = sc.sph[idx];
-      const f3 p = o + d * t;
-      n = sc.inv_r[idx] * (p - mk3(sp.x, sp.y, sp.z));
-      if (dot3(n, d) >= 0.0f) n = -n;
-      id = idx;
-      tt = t;
+  searcher<SEARCH, COUNTED> srch;
+  bool pending = false, in_trav = false, exhausted = false;
+  size_t ray = 0;
+
+  while (true) {
+    const unsigned long long m_trav = __ballot(in_trav);
+    const unsigned long long m_ready = __ballot(!in_trav && !exhausted);
+    if ((m_trav | m_ready) == 0ull) break;
+    const bool path_phase = m_trav == 0ull || __popcll(m_ready) >= A.vote;
+    if (!path_phase) {
+      RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
+      RT_COUNT(k, trav_lane_steps, in_trav ? 1u : 0u);
+      if (in_trav) in_trav = srch.step(tv, stack_col, k);
+      continue;
     }
-    A.id[i] = id;
-    A.t[i] = tt;
-    A.nrm[3 * i] = n.x;
-    A.nrm[3 * i + 1] = n.y;
-    A.nrm[3 * i + 2] = n.z;
+    RT_COUNT(k, path_wave_phases, (threadIdx.x & 63) == 0 ? 1u : 0u);
+    if (in_trav || exhausted) continue;
+    RT_COUNT(k, path_lane_phases, 1);
+    if (pending) {
+      pending = false;
+      float t;
+      int idx;
+      srch.finish(sc, t, idx, k);
+      const f3 o = srch.ts.o, d = srch.ts.d;
+      f3 n = mk3(0.0f, 0.0f, 0.0f);
+      int id = -1;
+      float tt = -1.0f;
+      if (t > 0.001f) {
+        RT_COUNT(k, hits, 1);
+        const float4 sp = sc.sph[idx];
+        const f3 p = o + d * t;
+        n = sc.inv_r[idx] * (p - mk3(sp.x, sp.y, sp.z));
+        if (dot3(n, d) >= 0.0f) n = -n;
+        id = idx;
+        tt = t;
+      }
+      A.id[ray] = id;
+      A.t[ray] = tt;
+      A.nrm[3 * ray] = n.x;
+      A.nrm[3 * ray + 1] = n.y;
+      A.nrm[3 * ray + 2] = n.z;
+    }
+    ray = (size_t)atomicAdd(A.queue, 1ull);
+    if (ray >= A.n) {
+      exhausted = true;
+    } else {
+      const f3 o = mk3(A.o_xyz[3 * ray], A.o_xyz[3 * ray + 1], A.o_xyz[3 * ray + 2]);
+      const f3 d = mk3(A.d_xyz[3 * ray], A.d_xyz[3 * ray + 1], A.d_xyz[3 * ray + 2]);
+      RT_COUNT(k, segments, 1);
+      in_trav = srch.begin(sc, tv, o, d, k);
+      pending = true;
+    }
   }
   flush_counters<COUNTED>(A.counters, k);
 }

@@ -200,151 +200,162 @@ struct tree_view {
   const int32_t* leaf_idx;
 };
 
+// A closest-hit search that can be advanced one node at a time, so that a wave
+// can interleave the traversal steps of some lanes with other work of others.
+//   begin()  exact tests of the spheres kept out of the tree, per-ray constants;
+//            returns true when step() must be called
+//   step()   one 4-wide node: four box tests, exact tests of the leaves among
+//            them, ordered descent; returns false when the search is over
+//   finish() the scan's answer (repeats the ray with the scan when flagged)
 template <bool PAD_RAY, bool PACKED, int STACK, bool COUNTED>
-RT_DEV void hit_bvh4(const scene_dev& sc, const tree_view& tv, f3 o, f3 d, trav_stack<PACKED> stk, float& t_out,
-                     int& i_out, lane_counters& k) {
-  const float a = dot3(d, d);
-  if (!(a > 0.0f) || !(a < __builtin_inff())) {  // zero, NaN or overflowing direction: the scan decides
-    hit_linear<COUNTED>(sc, o, d, t_out, i_out, k);
-    return;
-  }
+struct tree_search {
+  f3 o, d;
+  float a;
+  slab_consts sl;
   trav_candidate c;
-  c.best_t = __builtin_inff();
-  c.best_i = -1;
-  c.redo = false;
+  int cur, sp;
 
-  // spheres kept out of the tree: exact tests, wave-uniform index
-  for (int j = 0; j < sc.n_big; j++) consider_sphere<COUNTED>(sc.big_sph[j], sc.big_idx[j], o, d, a, c, k);
-
-  if (sc.n_leaf > 0) {
+  RT_DEV bool begin(const scene_dev& sc, const tree_view& tv, f3 origin, f3 dir, lane_counters& k) {
+    o = origin;
+    d = dir;
+    a = dot3(d, d);
+    c.best_t = __builtin_inff();
+    c.best_i = -1;
+    c.redo = false;
+    sp = 0;
+    if (!(a > 0.0f) || !(a < __builtin_inff())) {  // zero, NaN or overflowing direction: the scan decides
+      c.redo = true;
+      return false;
+    }
+    // spheres kept out of the tree: exact tests, wave-uniform index
+    for (int j = 0; j < sc.n_big; j++) consider_sphere<COUNTED>(sc.big_sph[j], sc.big_idx[j], o, d, a, c, k);
+    if (sc.n_leaf <= 0) return false;
     // Box tests only: a direction component closer to zero than 1e-20 is
     // treated as +-1e-20, which keeps every slab parameter finite (a ray
     // that flat is inside or outside the slab for its whole length either way).
-    const f3 inv_d = mk3(__builtin_amdgcn_rcpf(slab_dir(d.x)), __builtin_amdgcn_rcpf(slab_dir(d.y)),
-                         __builtin_amdgcn_rcpf(slab_dir(d.z)));
-    slab_consts sl;
-    sl.inv_d = inv_d;
-    if (PAD_RAY) make_slab_consts(sc, o, inv_d, a, c, sl);
-    int cur = sc.root;
+    sl.inv_d = mk3(__builtin_amdgcn_rcpf(slab_dir(d.x)), __builtin_amdgcn_rcpf(slab_dir(d.y)),
+                   __builtin_amdgcn_rcpf(slab_dir(d.z)));
+    if (PAD_RAY) make_slab_consts(sc, o, sl.inv_d, a, c, sl);
+    cur = sc.root;
     if (cur < 0) {  // a single sphere in the tree
       consider_sphere<COUNTED>(tv.leaf_sph[~cur], tv.leaf_idx[~cur], o, d, a, c, k);
-    } else {
-      int sp = 0;
-      while (true) {
-        const bvh4_node* nd = tv.nodes + cur;
-        const float4 lox = reinterpret_cast<const float4*>(nd)[0];
-        const float4 loy = reinterpret_cast<const float4*>(nd)[1];
-        const float4 loz = reinterpret_cast<const float4*>(nd)[2];
-        const float4 hix = reinterpret_cast<const float4*>(nd)[3];
-        const float4 hiy = reinterpret_cast<const float4*>(nd)[4];
-        const float4 hiz = reinterpret_cast<const float4*>(nd)[5];
-        const int4 ref = reinterpret_cast<const int4*>(nd)[6];
-        const int refs[4] = {ref.x, ref.y, ref.z, ref.w};
-        float tn[4], tf[4];
+      return false;
+    }
+    return true;
+  }
+
+  RT_DEV bool step(const tree_view& tv, trav_stack<PACKED> stk, lane_counters& k) {
+    const bvh4_node* nd = tv.nodes + cur;
+    const float4 lox = reinterpret_cast<const float4*>(nd)[0];
+    const float4 loy = reinterpret_cast<const float4*>(nd)[1];
+    const float4 loz = reinterpret_cast<const float4*>(nd)[2];
+    const float4 hix = reinterpret_cast<const float4*>(nd)[3];
+    const float4 hiy = reinterpret_cast<const float4*>(nd)[4];
+    const float4 hiz = reinterpret_cast<const float4*>(nd)[5];
+    const int4 ref = reinterpret_cast<const int4*>(nd)[6];
+    const int refs[4] = {ref.x, ref.y, ref.z, ref.w};
+    float tn[4], tf[4];
 #pragma unroll
-        for (int ch = 0; ch < 4; ch++) child_interval<PAD_RAY>(lox, loy, loz, hix, hiy, hiz, ch, o, sl, tn[ch], tf[ch]);
-        // leaves first: an exact hit shortens the ray for the boxes below
-        unsigned leaf_mask = 0;
+    for (int ch = 0; ch < 4; ch++) child_interval<PAD_RAY>(lox, loy, loz, hix, hiy, hiz, ch, o, sl, tn[ch], tf[ch]);
+    // leaves first: an exact hit shortens the ray for the boxes below
+    unsigned leaf_mask = 0;
 #pragma unroll
-        for (int ch = 0; ch < 4; ch++) {
-          const bool valid = refs[ch] != RT_REF_EMPTY;
-          RT_COUNT(k, node_tests, valid ? 1u : 0u);
-          if (valid && refs[ch] < 0 && tn[ch] <= tf[ch] && tf[ch] >= RT_T_FLOOR && tn[ch] <= c.best_t) leaf_mask |= 1u << ch;
-        }
-        while (leaf_mask) {
-          const int ch = __builtin_ctz(leaf_mask);
-          leaf_mask &= leaf_mask - 1;
-          const int r = ch == 0 ? refs[0] : ch == 1 ? refs[1] : ch == 2 ? refs[2] : refs[3];
-          const int pos = ~r;
-          consider_sphere<COUNTED>(tv.leaf_sph[pos], tv.leaf_idx[pos], o, d, a, c, k);
-        }
-        if (PACKED) {
-          uint32_t key[4];
+    for (int ch = 0; ch < 4; ch++) {
+      const bool valid = refs[ch] != RT_REF_EMPTY;
+      RT_COUNT(k, node_tests, valid ? 1u : 0u);
+      if (valid && refs[ch] < 0 && tn[ch] <= tf[ch] && tf[ch] >= RT_T_FLOOR && tn[ch] <= c.best_t) leaf_mask |= 1u << ch;
+    }
+    while (leaf_mask) {
+      const int ch = __builtin_ctz(leaf_mask);
+      leaf_mask &= leaf_mask - 1;
+      const int r = ch == 0 ? refs[0] : ch == 1 ? refs[1] : ch == 2 ? refs[2] : refs[3];
+      const int pos = ~r;
+      consider_sphere<COUNTED>(tv.leaf_sph[pos], tv.leaf_idx[pos], o, d, a, c, k);
+    }
+    if (PACKED) {
+      uint32_t key[4];
 #pragma unroll
-          for (int ch = 0; ch < 4; ch++) {
-            const bool go = refs[ch] >= 0 && tn[ch] <= tf[ch] && tf[ch] >= RT_T_FLOOR && tn[ch] <= c.best_t;
-            key[ch] = go ? trav_stack<true>::key(tn[ch], refs[ch]) : 0xFFFFFFFFu;
-          }
-          // sort the four keys ascending (invalid = all ones sinks to the end)
+      for (int ch = 0; ch < 4; ch++) {
+        const bool go = refs[ch] >= 0 && tn[ch] <= tf[ch] && tf[ch] >= RT_T_FLOOR && tn[ch] <= c.best_t;
+        key[ch] = go ? trav_stack<true>::key(tn[ch], refs[ch]) : 0xFFFFFFFFu;
+      }
+      // sort the four keys ascending (invalid = all ones sinks to the end)
 #define RT_CE(i, j)                               \
   do {                                            \
     const uint32_t lo_ = min(key[i], key[j]);     \
     key[j] = max(key[i], key[j]);                 \
     key[i] = lo_;                                 \
   } while (0)
-          RT_CE(0, 1); RT_CE(2, 3); RT_CE(0, 2); RT_CE(1, 3); RT_CE(1, 2);
+      RT_CE(0, 1); RT_CE(2, 3); RT_CE(0, 2); RT_CE(1, 3); RT_CE(1, 2);
 #undef RT_CE
-          // farthest first, so the nearest is popped first
+      // farthest first, so the nearest is popped first
 #pragma unroll
-          for (int e = 3; e >= 1; e--) {
-            if (key[e] != 0xFFFFFFFFu) {
-              if (sp < STACK) stk.col[sp * 64] = key[e];
-              else c.redo = true;
-              sp += sp < STACK ? 1 : 0;
-            }
-          }
-          if (key[0] != 0xFFFFFFFFu) {
-            cur = trav_stack<true>::key_ref(key[0]);
-            continue;
-          }
-          bool found = false;
-          while (sp > 0) {
-            sp--;
-            const uint32_t e = stk.col[sp * 64];
-            if (trav_stack<true>::key_tn(e) <= c.best_t) {
-              cur = trav_stack<true>::key_ref(e);
-              found = true;
-              break;
-            }
-          }
-          if (!found) break;
-        } else {
-          // nearest child continues, the others are pushed with their entry parameter
-          int near = -1;
-          float near_tn = __builtin_inff();
-          bool go[4];
-#pragma unroll
-          for (int ch = 0; ch < 4; ch++) {
-            go[ch] = refs[ch] >= 0 && tn[ch] <= tf[ch] && tf[ch] >= RT_T_FLOOR && tn[ch] <= c.best_t;
-            if (go[ch] && (near < 0 || tn[ch] < near_tn)) {
-              near = ch;
-              near_tn = tn[ch];
-            }
-          }
-#pragma unroll
-          for (int ch = 0; ch < 4; ch++) {
-            if (go[ch] && ch != near) {
-              if (sp < STACK) {
-                stk.col[sp * 128] = (uint32_t)refs[ch];
-                stk.col[sp * 128 + 64] = __float_as_uint(tn[ch]);
-                sp++;
-              } else {
-                c.redo = true;
-              }
-            }
-          }
-          if (near >= 0) {
-            cur = near == 0 ? refs[0] : near == 1 ? refs[1] : near == 2 ? refs[2] : refs[3];
-            continue;
-          }
-          bool found = false;
-          while (sp > 0) {
-            sp--;
-            if (__uint_as_float(stk.col[sp * 128 + 64]) <= c.best_t) {
-              cur = (int)stk.col[sp * 128];
-              found = true;
-              break;
-            }
-          }
-          if (!found) break;
+      for (int e = 3; e >= 1; e--) {
+        if (key[e] != 0xFFFFFFFFu) {
+          if (sp < STACK) stk.col[sp * 64] = key[e];
+          else c.redo = true;
+          sp += sp < STACK ? 1 : 0;
         }
       }
+      if (key[0] != 0xFFFFFFFFu) {
+        cur = trav_stack<true>::key_ref(key[0]);
+        return true;
+      }
+      while (sp > 0) {
+        sp--;
+        const uint32_t e = stk.col[sp * 64];
+        if (trav_stack<true>::key_tn(e) <= c.best_t) {
+          cur = trav_stack<true>::key_ref(e);
+          return true;
+        }
+      }
+      return false;
+    } else {
+      // nearest child continues, the others are pushed with their entry parameter
+      int near = -1;
+      float near_tn = __builtin_inff();
+      bool go[4];
+#pragma unroll
+      for (int ch = 0; ch < 4; ch++) {
+        go[ch] = refs[ch] >= 0 && tn[ch] <= tf[ch] && tf[ch] >= RT_T_FLOOR && tn[ch] <= c.best_t;
+        if (go[ch] && (near < 0 || tn[ch] < near_tn)) {
+          near = ch;
+          near_tn = tn[ch];
+        }
+      }
+#pragma unroll
+      for (int ch = 0; ch < 4; ch++) {
+        if (go[ch] && ch != near) {
+          if (sp < STACK) {
+            stk.col[sp * 128] = (uint32_t)refs[ch];
+            stk.col[sp * 128 + 64] = __float_as_uint(tn[ch]);
+            sp++;
+          } else {
+            c.redo = true;
+          }
+        }
+      }
+      if (near >= 0) {
+        cur = near == 0 ? refs[0] : near == 1 ? refs[1] : near == 2 ? refs[2] : refs[3];
+        return true;
+      }
+      while (sp > 0) {
+        sp--;
+        if (__uint_as_float(stk.col[sp * 128 + 64]) <= c.best_t) {
+          cur = (int)stk.col[sp * 128];
+          return true;
+        }
+      }
+      return false;
     }
   }
-  if (c.redo) {
-    hit_linear<COUNTED>(sc, o, d, t_out, i_out, k);
-    return;
+
+  RT_DEV void finish(const scene_dev& sc, float& t_out, int& i_out, lane_counters& k) {
+    if (c.redo) {
+      hit_linear<COUNTED>(sc, o, d, t_out, i_out, k);
+      return;
+    }
+    t_out = c.best_i >= 0 ? c.best_t : -1.0f;
+    i_out = c.best_i;
   }
-  t_out = c.best_i >= 0 ? c.best_t : -1.0f;
-  i_out = c.best_i;
-}
+};
