@@ -123,16 +123,12 @@ struct Rng {  // fs:28-30 xorshift32_state, plus the injected counter mode
   int mode;
 };
 
-inline uint32_t next_u32(Rng& s) {
-  if (s.mode == RT_RNG_XORSHIFT_REF) {  // fs:326-332
-    uint32_t x = s.a;
-    x ^= x << 13;
-    x ^= x >> 17;
-    x ^= x << 5;
-    return s.a = x;
-  }
-  s.a += 0x9E3779B9u;  // counter mode: Weyl step, then finalise a copy
-  return mix32(s.a);
+inline uint32_t next_u32(Rng& s) {  // fs:326-332; the counter mode draws from the same generator
+  uint32_t x = s.a;
+  x ^= x << 13;
+  x ^= x >> 17;
+  x ^= x << 5;
+  return s.a = x;
 }
 
 inline float rand_float(Rng& s) {  // fs:334-345
@@ -150,9 +146,13 @@ inline uint32_t cantor(uint32_t k1, uint32_t k2) {  // fs:394-398
   return x + k2;
 }
 
+// Counter mode: the xorshift32 state a camera sample starts from is a hash of
+// (seed, pixel, sample) alone, so a sample's stream does not depend on which
+// other samples were drawn before it.  Zero is xorshift's fixed point: avoided.
 inline uint32_t counter_key(uint32_t seed, uint32_t pixel, uint32_t sample) {
   uint32_t h = mix32(seed ^ mix32(pixel));
-  return mix32(h + sample * 0x9E3779B9u);
+  h = mix32(h + sample * 0x9E3779B9u);
+  return h ? h : 0x9E3779B9u;
 }
 
 struct Counters {

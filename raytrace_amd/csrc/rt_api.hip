@@ -66,7 +66,7 @@ struct dev_buf {
 
 // Largest dynamic LDS a launch may ask for (the CU has 160 KiB).
 constexpr size_t kMaxLdsBytes = 160 * 1024;
-// A tree is staged in LDS when nodes + leaves fit in this many bytes.
+// The linear scan stages its sphere records in LDS up to this many bytes.
 constexpr size_t kLdsTreeBudget = 64 * 1024;
 // Spheres with a radius above kBigFactor x the median radius stay out of the
 // tree (at most kMaxBig of them) and are tested exactly for every ray.
@@ -259,8 +259,20 @@ int build_lbvh(rt_ctx* c) {
 }
 
 // Which search the kernels use for the uploaded scene.
+scene_counts counts_of(const rt_ctx* c) {
+  scene_counts n;
+  n.n_nodes = c->n_nodes;
+  n.n_leaf = c->n_leaf;
+  n.n_spheres = c->n_spheres;
+  n.n_materials = c->n_materials;
+  return n;
+}
+
 int choose_search(const rt_ctx* c) {
-  if (c->accel != RT_ACCEL_LBVH || c->n_spheres < 1) return SEARCH_LINEAR;
+  const scene_counts n = counts_of(c);
+  if (c->accel != RT_ACCEL_LBVH || c->n_spheres < 1)
+    return search_scene_lds_bytes<SEARCH_LINEAR_LDS>(n) <= kLdsTreeBudget && c->n_spheres >= 1 ? SEARCH_LINEAR_LDS
+                                                                                               : SEARCH_LINEAR;
   bool pad_ray = true;
   if (c->n_leaf > 0) {
     // One pad per ray is worth it when the worst pad (ray origin about one
@@ -268,8 +280,8 @@ int choose_search(const rt_ctx* c) {
     const float extent = (c->root_hi[0] - c->root_lo[0]) + (c->root_hi[1] - c->root_lo[1]) + (c->root_hi[2] - c->root_lo[2]);
     pad_ray = RT_PAD_SCALE * extent < c->r_median;
   }
-  const size_t tree_bytes = (size_t)c->n_nodes * sizeof(bvh4_node) + (size_t)c->n_leaf * 20 + 16;
-  const bool lds = c->n_nodes <= 4096 && tree_bytes <= kLdsTreeBudget;
+  // tree + hit-record + material arrays must leave room for the stacks of 16 waves
+  const bool lds = c->n_nodes <= 4096 && search_lds_bytes<SEARCH_TREE_LDS_RAY>(n) <= kMaxLdsBytes - 4096;
   if (lds) return pad_ray ? SEARCH_TREE_LDS_RAY : SEARCH_TREE_LDS_NODE;
   return pad_ray ? SEARCH_TREE_GLB_RAY : SEARCH_TREE_GLB_NODE;
 }
@@ -277,6 +289,7 @@ int choose_search(const rt_ctx* c) {
 const char* search_name(int search, bool render) {
   switch (search) {
     case SEARCH_LINEAR: return render ? "rt_render_kernel<linear>" : "rt_trace_kernel<linear>";
+    case SEARCH_LINEAR_LDS: return render ? "rt_render_kernel<linear,lds>" : "rt_trace_kernel<linear,lds>";
     case SEARCH_TREE_LDS_RAY: return render ? "rt_render_kernel<lbvh4,lds,pad_ray>" : "rt_trace_kernel<lbvh4,lds,pad_ray>";
     case SEARCH_TREE_LDS_NODE: return render ? "rt_render_kernel<lbvh4,lds,pad_node>" : "rt_trace_kernel<lbvh4,lds,pad_node>";
     case SEARCH_TREE_GLB_RAY: return render ? "rt_render_kernel<lbvh4,hbm,pad_ray>" : "rt_trace_kernel<lbvh4,hbm,pad_ray>";
@@ -338,7 +351,7 @@ template <int SEARCH, int RNG, bool COUNTED>
 hipError_t launch_render_one(const rt_ctx* c, const rt_params* p, hipStream_t st, const render_args& a) {
   using T = search_traits<SEARCH>;
   const int tw = p->tile_x1 - p->tile_x0, th = p->tile_y1 - p->tile_y0;
-  const size_t lds = search_lds_bytes<SEARCH>(c->n_nodes, c->n_leaf);
+  const size_t lds = search_lds_bytes<SEARCH>(counts_of(c));
   hipError_t e = allow_lds(rt_render_kernel<SEARCH, RNG, COUNTED>, lds);
   if (e != hipSuccess) return e;
   int per_cu = 0;
@@ -366,7 +379,7 @@ hipError_t launch_render(const rt_ctx* c, const rt_params* p, bool counted, hipS
 template <int SEARCH, bool COUNTED>
 hipError_t launch_trace_one(const rt_ctx* c, hipStream_t st, const trace_args& a) {
   using T = search_traits<SEARCH>;
-  const size_t lds = search_lds_bytes<SEARCH>(c->n_nodes, c->n_leaf);
+  const size_t lds = search_lds_bytes<SEARCH>(counts_of(c));
   hipError_t e = allow_lds(rt_trace_kernel<SEARCH, COUNTED>, lds);
   if (e != hipSuccess) return e;
   int per_cu = 0;
@@ -442,6 +455,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       case SEARCH_TREE_LDS_NODE: return launch_render<SEARCH_TREE_LDS_NODE>(c, rp, counted, c->stream, ra);
       case SEARCH_TREE_GLB_RAY: return launch_render<SEARCH_TREE_GLB_RAY>(c, rp, counted, c->stream, ra);
       case SEARCH_TREE_GLB_NODE: return launch_render<SEARCH_TREE_GLB_NODE>(c, rp, counted, c->stream, ra);
+      case SEARCH_LINEAR_LDS: return launch_render<SEARCH_LINEAR_LDS>(c, rp, counted, c->stream, ra);
       default: return launch_render<SEARCH_LINEAR>(c, rp, counted, c->stream, ra);
     }
   };
@@ -663,9 +677,6 @@ int rt_scene_upload(rt_ctx* c, const void* spheres_std140, int n_spheres, const 
     if (rc) return rc;
   }
   c->search = choose_search(c);
-  if (search_lds_bytes<SEARCH_TREE_LDS_RAY>(c->n_nodes, c->n_leaf) > kMaxLdsBytes &&
-      (c->search == SEARCH_TREE_LDS_RAY || c->search == SEARCH_TREE_LDS_NODE))
-    return fail(RT_ERR_STATE, "internal: LDS tree does not fit");
   c->have_scene = true;
   return RT_OK;
 }
@@ -761,6 +772,7 @@ int rt_trace_batch_device(rt_ctx* c, const float* o_xyz, const float* d_xyz, siz
     case SEARCH_TREE_LDS_NODE: e = launch_trace<SEARCH_TREE_LDS_NODE>(c, counted != 0, c->stream, a); break;
     case SEARCH_TREE_GLB_RAY: e = launch_trace<SEARCH_TREE_GLB_RAY>(c, counted != 0, c->stream, a); break;
     case SEARCH_TREE_GLB_NODE: e = launch_trace<SEARCH_TREE_GLB_NODE>(c, counted != 0, c->stream, a); break;
+    case SEARCH_LINEAR_LDS: e = launch_trace<SEARCH_LINEAR_LDS>(c, counted != 0, c->stream, a); break;
     default: e = launch_trace<SEARCH_LINEAR>(c, counted != 0, c->stream, a); break;
   }
   if (e != hipSuccess) return fail(RT_ERR_DEVICE, "trace launch: %s", hipGetErrorString(e));

@@ -61,21 +61,17 @@ RT_DEV uint32_t mix32(uint32_t x) {
   return x;
 }
 
-// RNG == RT_RNG_XORSHIFT_REF: xorshift32 13/17/5 on the running state.
-// RNG == RT_RNG_COUNTER: Weyl step of the state, output = finaliser of it.
+// xorshift32 13/17/5 on the running state (fs:326-332).  Both RNG modes draw
+// from it; they differ in where the state comes from: RT_RNG_XORSHIFT_REF seeds
+// it once per pixel, RT_RNG_COUNTER re-keys it per (seed, pixel, sample).
 template <int RNG>
 RT_DEV uint32_t rng_next(uint32_t& a) {
-  if (RNG == RT_RNG_XORSHIFT_REF) {
-    uint32_t x = a;
-    x ^= x << 13;
-    x ^= x >> 17;
-    x ^= x << 5;
-    a = x;
-    return x;
-  } else {
-    a += 0x9E3779B9u;
-    return mix32(a);
-  }
+  uint32_t x = a;
+  x ^= x << 13;
+  x ^= x >> 17;
+  x ^= x << 5;
+  a = x;
+  return x;
 }
 
 template <int RNG>
@@ -93,7 +89,8 @@ RT_DEV uint32_t cantor_pair(uint32_t k1, uint32_t k2) {
 
 RT_DEV uint32_t counter_key(uint32_t seed, uint32_t pixel, uint32_t sample) {
   uint32_t h = mix32(seed ^ mix32(pixel));
-  return mix32(h + sample * 0x9E3779B9u);
+  h = mix32(h + sample * 0x9E3779B9u);
+  return h ? h : 0x9E3779B9u;  // zero is xorshift's fixed point
 }
 
 // Per-lane work counters, kept in registers and flushed once per lane.

@@ -5,9 +5,10 @@
 #include "rt_scene_dev.cuh"
 
 // How a kernel finds the closest hit.
-//   SEARCH_LINEAR      the reference's scan over every sphere
-//   SEARCH_TREE_LDS_*  4-wide LBVH staged in LDS (small scenes): one copy per
-//                      1024-thread workgroup, one-word stack entries
+//   SEARCH_LINEAR      the reference's scan over every sphere, records by scalar loads
+//   SEARCH_LINEAR_LDS  the same scan with the records staged in LDS (scenes up to 4096 spheres)
+//   SEARCH_TREE_LDS_*  4-wide LBVH, hit-record and material arrays staged in LDS (small
+//                      scenes): one copy per 1024-thread workgroup, one-word stack entries
 //   SEARCH_TREE_GLB_*  4-wide LBVH read from HBM / caches (large scenes)
 //   *_RAY / *_NODE     the box-growing rule (rt_scene_dev.cuh)
 enum {
@@ -15,29 +16,44 @@ enum {
   SEARCH_TREE_LDS_RAY = 1,
   SEARCH_TREE_LDS_NODE = 2,
   SEARCH_TREE_GLB_RAY = 3,
-  SEARCH_TREE_GLB_NODE = 4
+  SEARCH_TREE_GLB_NODE = 4,
+  SEARCH_LINEAR_LDS = 5
 };
 
 template <int SEARCH>
 struct search_traits {
-  static constexpr bool tree = SEARCH != SEARCH_LINEAR;
+  static constexpr bool tree = SEARCH >= SEARCH_TREE_LDS_RAY && SEARCH <= SEARCH_TREE_GLB_NODE;
   static constexpr bool lds = SEARCH == SEARCH_TREE_LDS_RAY || SEARCH == SEARCH_TREE_LDS_NODE;
+  static constexpr bool scan_lds = SEARCH == SEARCH_LINEAR_LDS;
   static constexpr bool pad_ray = SEARCH == SEARCH_TREE_LDS_RAY || SEARCH == SEARCH_TREE_GLB_RAY;
   static constexpr int waves = lds ? 16 : 4;       // waves per workgroup
   static constexpr int threads = waves * 64;
-  static constexpr int waves_x = lds ? 4 : 2;      // 8x8-pixel wave tiles across a workgroup tile
-  static constexpr int tile = waves_x * 8;         // workgroup tile edge in pixels
   static constexpr int stack = lds ? 16 : 32;      // entries per lane
   static constexpr int stack_words = !tree ? 0 : (lds ? stack * 64 : stack * 128);  // per wave
 };
 
-// Bytes of dynamic LDS a launch needs.
+struct scene_counts {
+  int n_nodes, n_leaf, n_spheres, n_materials;
+};
+
+inline size_t pad16(size_t b) { return (b + 15) & ~(size_t)15; }
+
+// Bytes of the scene copy a search keeps in LDS.
 template <int SEARCH>
-inline size_t search_lds_bytes(int n_nodes, int n_leaf) {
+inline size_t search_scene_lds_bytes(const scene_counts& n) {
   using T = search_traits<SEARCH>;
-  size_t b = (size_t)T::waves * T::stack_words * 4;
-  if (T::lds) b += (size_t)n_nodes * sizeof(bvh4_node) + (size_t)n_leaf * 16 + (((size_t)n_leaf * 4 + 15) & ~(size_t)15);
-  return b;
+  if (T::scan_lds) return (size_t)n.n_spheres * 16;
+  if (!T::lds) return 0;
+  return (size_t)n.n_nodes * sizeof(bvh4_node) + (size_t)n.n_leaf * 16 + pad16((size_t)n.n_leaf * 4) +
+         (size_t)n.n_spheres * 16 + 2 * pad16((size_t)n.n_spheres * 4) + (size_t)n.n_materials * 16 +
+         pad16((size_t)n.n_materials * 4);
+}
+
+// Bytes of dynamic LDS a launch needs (scene copy + traversal stacks).
+template <int SEARCH>
+inline size_t search_lds_bytes(const scene_counts& n) {
+  using T = search_traits<SEARCH>;
+  return search_scene_lds_bytes<SEARCH>(n) + (size_t)T::waves * T::stack_words * 4;
 }
 
 struct render_args {
@@ -80,35 +96,57 @@ RT_DEV void flush_counters(unsigned long long* g, const lane_counters& k) {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds[];
 
-// Carve the dynamic LDS: [nodes | leaf spheres | leaf indices] (LDS searches
-// only) then the traversal stacks; copy the tree in.  Every thread of the
-// workgroup must call this before the first search.
+RT_DEV size_t pad16_dev(size_t b) { return (b + 15) & ~(size_t)15; }
+
+// Carve the dynamic LDS — the scene copy of the search (tree, hit-record and
+// material arrays; or the scan's sphere records), then the traversal stacks —
+// and copy the scene in.  Every thread of the workgroup must call this before
+// the first search.
 template <int SEARCH>
-RT_DEV void search_setup(const scene_dev& sc, tree_view& tv, uint32_t*& stack_col) {
+RT_DEV void search_setup(const scene_dev& sc, scene_view& sv, uint32_t*& stack_col) {
   using T = search_traits<SEARCH>;
-  tv.nodes = sc.nodes;
-  tv.leaf_sph = sc.leaf_sph;
-  tv.leaf_idx = sc.leaf_idx;
+  sv.nodes = sc.nodes;
+  sv.leaf_sph = sc.leaf_sph;
+  sv.leaf_idx = sc.leaf_idx;
+  sv.scan_sph = sc.sph;
+  sv.sph = sc.sph;
+  sv.inv_r = sc.inv_r;
+  sv.sph_mat = sc.sph_mat;
+  sv.mat_a = sc.mat_a;
+  sv.mat_type = sc.mat_type;
   stack_col = nullptr;
-  if (!T::tree) return;
   unsigned char* base = rt_lds;
+  if (T::scan_lds) {
+    float4* d = reinterpret_cast<float4*>(base);
+    for (int i = threadIdx.x; i < sc.n_spheres; i += T::threads) d[i] = sc.sph[i];
+    sv.scan_sph = d;
+    __syncthreads();
+    return;
+  }
+  if (!T::tree) return;
   if (T::lds) {
-    const size_t node_bytes = (size_t)sc.n_nodes * sizeof(bvh4_node);
-    const size_t leaf_bytes = (size_t)sc.n_leaf * 16;
-    const size_t idx_bytes = ((size_t)sc.n_leaf * 4 + 15) & ~(size_t)15;
-    float4* dn = reinterpret_cast<float4*>(base);
-    float4* dl = reinterpret_cast<float4*>(base + node_bytes);
-    int32_t* di = reinterpret_cast<int32_t*>(base + node_bytes + leaf_bytes);
-    const float4* sn = reinterpret_cast<const float4*>(sc.nodes);
-    for (int i = threadIdx.x; i < sc.n_nodes * 8; i += T::threads) dn[i] = sn[i];
-    for (int i = threadIdx.x; i < sc.n_leaf; i += T::threads) {
-      dl[i] = sc.leaf_sph[i];
-      di[i] = sc.leaf_idx[i];
+    {
+      float4* d = reinterpret_cast<float4*>(base);
+      const float4* src = reinterpret_cast<const float4*>(sc.nodes);
+      for (int i = threadIdx.x; i < sc.n_nodes * 8; i += T::threads) d[i] = src[i];
+      sv.nodes = reinterpret_cast<const bvh4_node*>(d);
+      base += (size_t)sc.n_nodes * sizeof(bvh4_node);
     }
-    tv.nodes = reinterpret_cast<const bvh4_node*>(dn);
-    tv.leaf_sph = dl;
-    tv.leaf_idx = di;
-    base += node_bytes + leaf_bytes + idx_bytes;
+#define RT_LDS_COPY(field, type, count)                                       \
+  {                                                                           \
+    type* d = reinterpret_cast<type*>(base);                                  \
+    for (int i = threadIdx.x; i < (count); i += T::threads) d[i] = sc.field[i]; \
+    sv.field = d;                                                             \
+    base += pad16_dev((size_t)(count) * sizeof(type));                        \
+  }
+    RT_LDS_COPY(leaf_sph, float4, sc.n_leaf)
+    RT_LDS_COPY(leaf_idx, int32_t, sc.n_leaf)
+    RT_LDS_COPY(sph, float4, sc.n_spheres)
+    RT_LDS_COPY(inv_r, float, sc.n_spheres)
+    RT_LDS_COPY(sph_mat, int32_t, sc.n_spheres)
+    RT_LDS_COPY(mat_a, float4, sc.n_materials)
+    RT_LDS_COPY(mat_type, int32_t, sc.n_materials)
+#undef RT_LDS_COPY
     __syncthreads();
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -116,24 +154,26 @@ RT_DEV void search_setup(const scene_dev& sc, tree_view& tv, uint32_t*& stack_co
 }
 
 // The search object of a kernel: the stepwise tree search, or for the linear
-// scan an object whose begin() does the whole scan.
+// scan an object whose finish() does the whole scan.
 template <int SEARCH, bool COUNTED>
 struct searcher {
   using T = search_traits<SEARCH>;
   tree_search<T::pad_ray, T::lds, T::stack, COUNTED> ts;
-  RT_DEV bool begin(const scene_dev& sc, const tree_view& tv, f3 o, f3 d, lane_counters& k) {
-    if (T::tree) return ts.begin(sc, tv, o, d, k);
+  RT_DEV bool begin(const scene_dev& sc, const scene_view& sv, f3 o, f3 d, lane_counters& k) {
+    if (T::tree) return ts.begin(sc, sv, o, d, k);
     ts.o = o;
     ts.d = d;
     ts.c.redo = true;  // finish() runs the scan
     return false;
   }
-  RT_DEV bool step(const tree_view& tv, uint32_t* stack_col, lane_counters& k) {
+  RT_DEV bool step(const scene_view& sv, uint32_t* stack_col, lane_counters& k) {
     trav_stack<T::lds> stk;
     stk.col = stack_col;
-    return ts.step(tv, stk, k);
+    return ts.step(sv, stk, k);
   }
-  RT_DEV void finish(const scene_dev& sc, float& t, int& idx, lane_counters& k) { ts.finish(sc, t, idx, k); }
+  RT_DEV void finish(const scene_dev& sc, const scene_view& sv, float& t, int& idx, lane_counters& k) {
+    ts.finish(sc, sv, t, idx, k);
+  }
 };
 
 // Lanes of a wave that are ready for their path phase wait until this many of
@@ -162,9 +202,9 @@ template <int SEARCH, int RNG, bool COUNTED>
 __global__ __launch_bounds__(search_traits<SEARCH>::threads) void rt_render_kernel(const render_args A) {
   const rt_params& P = A.p;
   const scene_dev& sc = A.sc;
-  tree_view tv;
+  scene_view sv;
   uint32_t* stack_col;
-  search_setup<SEARCH>(sc, tv, stack_col);
+  search_setup<SEARCH>(sc, sv, stack_col);
 
   const int tw = P.tile_x1 - P.tile_x0, th = P.tile_y1 - P.tile_y0;
   const int tiles_x = (tw + 7) >> 3, tiles_y = (th + 7) >> 3;
@@ -217,7 +257,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads) void rt_render_kern
     if (!path_phase) {
       RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
       RT_COUNT(k, trav_lane_steps, in_trav ? 1u : 0u);
-      if (in_trav) in_trav = srch.step(tv, stack_col, k);  // `pending` (set at begin) marks the result as unread
+      if (in_trav) in_trav = srch.step(sv, stack_col, k);  // `pending` (set at begin) marks the result as unread
       continue;
     }
     RT_COUNT(k, path_wave_phases, (threadIdx.x & 63) == 0 ? 1u : 0u);
@@ -229,25 +269,25 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads) void rt_render_kern
       pending = false;
       float t;
       int idx;
-      srch.finish(sc, t, idx, k);
+      srch.finish(sc, sv, t, idx, k);
       const f3 o = srch.ts.o;
       f3 d = srch.ts.d;
       bool cont;
       f3 next_o = o;
       if (t > 0.001f) {  // fs:186-196
         RT_COUNT(k, hits, 1);
-        const float4 sp = sc.sph[idx];
+        const float4 sp = sv.sph[idx];
         hit_rec h;
         h.point = o + d * t;
-        h.normal = sc.inv_r[idx] * (h.point - mk3(sp.x, sp.y, sp.z));
+        h.normal = sv.inv_r[idx] * (h.point - mk3(sp.x, sp.y, sp.z));
         h.interior = false;
         if (dot3(h.normal, d) >= 0.0f) {
           h.normal = -h.normal;
           h.interior = true;
         }
-        h.mat = sc.sph_mat[idx];
-        const float4 ma = sc.mat_a[h.mat];
-        const int type = sc.mat_type[h.mat];
+        h.mat = sv.sph_mat[idx];
+        const float4 ma = sv.mat_a[h.mat];
+        const int type = sv.mat_type[h.mat];
         next_o = h.point;  // fs:211-212
         count = count + 1u;
         cont = shade_hit<RNG, COUNTED>(h, type, ma.w, mk3(ma.x, ma.y, ma.z), d, alb, rng, k);
@@ -339,7 +379,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads) void rt_render_kern
     if (start_segment) {
       RT_COUNT(k, segments, 1);
       pixel_segments++;
-      in_trav = srch.begin(sc, tv, srch.ts.o, srch.ts.d, k);
+      in_trav = srch.begin(sc, sv, srch.ts.o, srch.ts.d, k);
       pending = true;
     }
   }
@@ -365,9 +405,9 @@ struct trace_args {
 template <int SEARCH, bool COUNTED>
 __global__ __launch_bounds__(search_traits<SEARCH>::threads) void rt_trace_kernel(const trace_args A) {
   const scene_dev& sc = A.sc;
-  tree_view tv;
+  scene_view sv;
   uint32_t* stack_col;
-  search_setup<SEARCH>(sc, tv, stack_col);
+  search_setup<SEARCH>(sc, sv, stack_col);
   lane_counters k = {};
   searcher<SEARCH, COUNTED> srch;
   bool pending = false, in_trav = false, exhausted = false;
@@ -381,7 +421,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads) void rt_trace_kerne
     if (!path_phase) {
       RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
       RT_COUNT(k, trav_lane_steps, in_trav ? 1u : 0u);
-      if (in_trav) in_trav = srch.step(tv, stack_col, k);
+      if (in_trav) in_trav = srch.step(sv, stack_col, k);
       continue;
     }
     RT_COUNT(k, path_wave_phases, (threadIdx.x & 63) == 0 ? 1u : 0u);
@@ -391,16 +431,16 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads) void rt_trace_kerne
       pending = false;
       float t;
       int idx;
-      srch.finish(sc, t, idx, k);
+      srch.finish(sc, sv, t, idx, k);
       const f3 o = srch.ts.o, d = srch.ts.d;
       f3 n = mk3(0.0f, 0.0f, 0.0f);
       int id = -1;
       float tt = -1.0f;
       if (t > 0.001f) {
         RT_COUNT(k, hits, 1);
-        const float4 sp = sc.sph[idx];
+        const float4 sp = sv.sph[idx];
         const f3 p = o + d * t;
-        n = sc.inv_r[idx] * (p - mk3(sp.x, sp.y, sp.z));
+        n = sv.inv_r[idx] * (p - mk3(sp.x, sp.y, sp.z));
         if (dot3(n, d) >= 0.0f) n = -n;
         id = idx;
         tt = t;
@@ -418,7 +458,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads) void rt_trace_kerne
       const f3 o = mk3(A.o_xyz[3 * ray], A.o_xyz[3 * ray + 1], A.o_xyz[3 * ray + 2]);
       const f3 d = mk3(A.d_xyz[3 * ray], A.d_xyz[3 * ray + 1], A.d_xyz[3 * ray + 2]);
       RT_COUNT(k, segments, 1);
-      in_trav = srch.begin(sc, tv, o, d, k);
+      in_trav = srch.begin(sc, sv, o, d, k);
       pending = true;
     }
   }

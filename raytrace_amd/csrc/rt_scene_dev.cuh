@@ -42,29 +42,61 @@ struct scene_dev {
   float abs_max;            // largest |coordinate| sum of the root box corners
 };
 
+// The arrays a kernel actually reads: the HBM originals or their LDS copies.
+struct scene_view {
+  const bvh4_node* nodes;
+  const float4* leaf_sph;
+  const int32_t* leaf_idx;
+  const float4* scan_sph;   // upload-order spheres for the linear scan
+  // hit record and shading, upload order
+  const float4* sph;
+  const float* inv_r;
+  const int32_t* sph_mat;
+  const float4* mat_a;
+  const int32_t* mat_type;
+};
+
 // ---------------------------------------------------------------------------
 // Linear scan: hit_any of testFragment.fs:165-199.  The loop index is the same
-// in every lane, so the sphere record is fetched once per wave through the
-// scalar cache and enters the VALU as scalar operands.
+// in every lane, so a sphere record is one broadcast LDS read (or one scalar
+// load when the scene is too large for LDS) per wave.
+//
+// The expensive part of hit_sphere is the correctly rounded sqrt and divide of
+// the roots; they only matter when the sphere can replace the current closest
+// hit.  The accepted root is never below the near root, so a sphere whose near
+// root — estimated with the hardware's 1-ulp sqrt / rcp and a slack of 8u
+// times the terms that were subtracted — already lies beyond the closest hit
+// cannot satisfy "new_t < t" (fs:180) and is skipped without computing it.
 // Returns t (-1 or a stuck NaN mean "no hit": the caller tests t > 0.001) and
 // the index that produced it.
 // ---------------------------------------------------------------------------
 template <bool COUNTED>
-RT_DEV void hit_linear(const scene_dev& sc, f3 o, f3 d, float& t_out, int& i_out, lane_counters& k) {
+RT_DEV void hit_linear(const float4* sph, int n, f3 o, f3 d, float& t_out, int& i_out, lane_counters& k) {
   const float a = dot3(d, d);
+  const bool can_estimate = a > 1e-30f && a < 1e30f;
+  const float rcp_a = __builtin_amdgcn_rcpf(a);
   float best_t = -1.0f;
   int best_i = -1;
-  const int n = sc.n_spheres;
   RT_COUNT(k, sphere_tests, (uint32_t)n);
+#pragma unroll 4
   for (int i = 0; i < n; i++) {
-    const float4 s = sc.sph[i];
+    const float4 s = sph[i];
     float h, disc;
     sphere_disc(s.x, s.y, s.z, s.w, o, d, a, h, disc);
     if (disc >= 0.0f) {
-      float t = sphere_roots<COUNTED>(h, disc, a, k);
-      if (best_t < 0.0f || (t < best_t && t > 0.001f)) {  // fs:180
-        best_t = t;
-        best_i = i;
+      bool need_exact = true;
+      if (can_estimate && !(best_t < 0.0f)) {
+        const float sq = __builtin_amdgcn_sqrtf(disc);
+        const float near_t = (h - sq) * rcp_a;
+        const float slack = 1.0e-6f * ((fabsf(h) + sq) * rcp_a);
+        need_exact = near_t - slack < best_t;
+      }
+      if (need_exact) {
+        float t = sphere_roots<COUNTED>(h, disc, a, k);
+        if (best_t < 0.0f || (t < best_t && t > 0.001f)) {  // fs:180
+          best_t = t;
+          best_i = i;
+        }
       }
     }
   }
@@ -141,23 +173,19 @@ RT_DEV float far_corner_l1(const float* lo, const float* hi, f3 o) {
 
 RT_DEV void make_slab_consts(const scene_dev& sc, f3 o, f3 inv_d, float a, const trav_candidate& c, slab_consts& s) {
   float D = far_corner_l1(sc.root_lo, sc.root_hi, o);
-  if (c.best_i >= 0) D = fminf(D, 1.003f * (c.best_t * sqrtf(a) + 2.0f * sc.r_max));
+  // |d| from the 1-ulp hardware sqrt: the 1.003 factor absorbs it
+  if (c.best_i >= 0) D = fminf(D, 1.003f * (c.best_t * __builtin_amdgcn_sqrtf(a) + 2.0f * sc.r_max));
   const float pad = RT_PAD_SCALE * D + 2.384186e-7f * ((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z) + sc.abs_max);
   s.inv_d = inv_d;
   s.k_lo = mk3(-(o.x + pad) * inv_d.x, -(o.y + pad) * inv_d.y, -(o.z + pad) * inv_d.z);
   s.k_hi = mk3(-(o.x - pad) * inv_d.x, -(o.y - pad) * inv_d.y, -(o.z - pad) * inv_d.z);
 }
 
-// Entry / exit parameters of the grown box of child `c` of a node.
+// Parameter interval of the ray inside the grown box of one child, clipped to
+// [RT_T_FLOOR, limit]: the child is worth visiting iff tn <= tf.
 template <bool PAD_RAY>
-RT_DEV void child_interval(const float4& lox, const float4& loy, const float4& loz, const float4& hix, const float4& hiy,
-                           const float4& hiz, int c, f3 o, const slab_consts& s, float& tn, float& tf) {
-  const float lx = c == 0 ? lox.x : c == 1 ? lox.y : c == 2 ? lox.z : lox.w;
-  const float ly = c == 0 ? loy.x : c == 1 ? loy.y : c == 2 ? loy.z : loy.w;
-  const float lz = c == 0 ? loz.x : c == 1 ? loz.y : c == 2 ? loz.z : loz.w;
-  const float hx = c == 0 ? hix.x : c == 1 ? hix.y : c == 2 ? hix.z : hix.w;
-  const float hy = c == 0 ? hiy.x : c == 1 ? hiy.y : c == 2 ? hiy.z : hiy.w;
-  const float hz = c == 0 ? hiz.x : c == 1 ? hiz.y : c == 2 ? hiz.z : hiz.w;
+RT_DEV void child_interval(float lx, float ly, float lz, float hx, float hy, float hz, f3 o, const slab_consts& s,
+                           float limit, float& tn, float& tf) {
   float t0x, t1x, t0y, t1y, t0z, t1z;
   if (PAD_RAY) {
     t0x = __builtin_fmaf(lx, s.inv_d.x, s.k_lo.x); t1x = __builtin_fmaf(hx, s.inv_d.x, s.k_hi.x);
@@ -170,8 +198,8 @@ RT_DEV void child_interval(const float4& lox, const float4& loy, const float4& l
     t0y = (ay - pad) * s.inv_d.y; t1y = (by + pad) * s.inv_d.y;
     t0z = (az - pad) * s.inv_d.z; t1z = (bz + pad) * s.inv_d.z;
   }
-  tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
-  tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+  tn = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), RT_T_FLOOR);
+  tf = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), limit);
 }
 
 // Traversal stack entry.  PACKED (trees of at most 4096 nodes): one word, the
@@ -183,7 +211,7 @@ struct trav_stack;
 template <>
 struct trav_stack<true> {
   uint32_t* col;  // this lane's column: element e at col[e * 64]
-  RT_DEV static uint32_t key(float tn, int ref) { return (__float_as_uint(fmaxf(tn, 0.0f)) & 0xFFFFF000u) | (uint32_t)ref; }
+  RT_DEV static uint32_t key(float tn, int ref) { return (__float_as_uint(tn) & 0xFFFFF000u) | (uint32_t)ref; }
   RT_DEV static float key_tn(uint32_t k) { return __uint_as_float(k & 0xFFFFF000u); }
   RT_DEV static int key_ref(uint32_t k) { return (int)(k & 0xFFFu); }
 };
@@ -191,13 +219,6 @@ struct trav_stack<true> {
 template <>
 struct trav_stack<false> {
   uint32_t* col;  // refs at col[e * 128], entry parameters at col[e * 128 + 64]
-};
-
-// Memory views the traversal reads: the same arrays either in HBM or staged in LDS.
-struct tree_view {
-  const bvh4_node* nodes;
-  const float4* leaf_sph;
-  const int32_t* leaf_idx;
 };
 
 // A closest-hit search that can be advanced one node at a time, so that a wave
@@ -215,7 +236,7 @@ struct tree_search {
   trav_candidate c;
   int cur, sp;
 
-  RT_DEV bool begin(const scene_dev& sc, const tree_view& tv, f3 origin, f3 dir, lane_counters& k) {
+  RT_DEV bool begin(const scene_dev& sc, const scene_view& sv, f3 origin, f3 dir, lane_counters& k) {
     o = origin;
     d = dir;
     a = dot3(d, d);
@@ -238,14 +259,14 @@ struct tree_search {
     if (PAD_RAY) make_slab_consts(sc, o, sl.inv_d, a, c, sl);
     cur = sc.root;
     if (cur < 0) {  // a single sphere in the tree
-      consider_sphere<COUNTED>(tv.leaf_sph[~cur], tv.leaf_idx[~cur], o, d, a, c, k);
+      consider_sphere<COUNTED>(sv.leaf_sph[~cur], sv.leaf_idx[~cur], o, d, a, c, k);
       return false;
     }
     return true;
   }
 
-  RT_DEV bool step(const tree_view& tv, trav_stack<PACKED> stk, lane_counters& k) {
-    const bvh4_node* nd = tv.nodes + cur;
+  RT_DEV bool step(const scene_view& sv, trav_stack<PACKED> stk, lane_counters& k) {
+    const bvh4_node* nd = sv.nodes + cur;
     const float4 lox = reinterpret_cast<const float4*>(nd)[0];
     const float4 loy = reinterpret_cast<const float4*>(nd)[1];
     const float4 loz = reinterpret_cast<const float4*>(nd)[2];
@@ -255,28 +276,31 @@ struct tree_search {
     const int4 ref = reinterpret_cast<const int4*>(nd)[6];
     const int refs[4] = {ref.x, ref.y, ref.z, ref.w};
     float tn[4], tf[4];
-#pragma unroll
-    for (int ch = 0; ch < 4; ch++) child_interval<PAD_RAY>(lox, loy, loz, hix, hiy, hiz, ch, o, sl, tn[ch], tf[ch]);
-    // leaves first: an exact hit shortens the ray for the boxes below
+    child_interval<PAD_RAY>(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, o, sl, c.best_t, tn[0], tf[0]);
+    child_interval<PAD_RAY>(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, o, sl, c.best_t, tn[1], tf[1]);
+    child_interval<PAD_RAY>(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, o, sl, c.best_t, tn[2], tf[2]);
+    child_interval<PAD_RAY>(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, o, sl, c.best_t, tn[3], tf[3]);
+    bool ok[4];
     unsigned leaf_mask = 0;
 #pragma unroll
     for (int ch = 0; ch < 4; ch++) {
-      const bool valid = refs[ch] != RT_REF_EMPTY;
-      RT_COUNT(k, node_tests, valid ? 1u : 0u);
-      if (valid && refs[ch] < 0 && tn[ch] <= tf[ch] && tf[ch] >= RT_T_FLOOR && tn[ch] <= c.best_t) leaf_mask |= 1u << ch;
+      ok[ch] = tn[ch] <= tf[ch] && refs[ch] != RT_REF_EMPTY;
+      RT_COUNT(k, node_tests, refs[ch] != RT_REF_EMPTY ? 1u : 0u);
+      if (ok[ch] && refs[ch] < 0) leaf_mask |= 1u << ch;
     }
+    // leaves first: an exact hit shortens the ray for the boxes below
     while (leaf_mask) {
       const int ch = __builtin_ctz(leaf_mask);
       leaf_mask &= leaf_mask - 1;
       const int r = ch == 0 ? refs[0] : ch == 1 ? refs[1] : ch == 2 ? refs[2] : refs[3];
       const int pos = ~r;
-      consider_sphere<COUNTED>(tv.leaf_sph[pos], tv.leaf_idx[pos], o, d, a, c, k);
+      consider_sphere<COUNTED>(sv.leaf_sph[pos], sv.leaf_idx[pos], o, d, a, c, k);
     }
     if (PACKED) {
       uint32_t key[4];
 #pragma unroll
       for (int ch = 0; ch < 4; ch++) {
-        const bool go = refs[ch] >= 0 && tn[ch] <= tf[ch] && tf[ch] >= RT_T_FLOOR && tn[ch] <= c.best_t;
+        const bool go = ok[ch] && refs[ch] >= 0 && tn[ch] <= c.best_t;
         key[ch] = go ? trav_stack<true>::key(tn[ch], refs[ch]) : 0xFFFFFFFFu;
       }
       // sort the four keys ascending (invalid = all ones sinks to the end)
@@ -317,7 +341,7 @@ struct tree_search {
       bool go[4];
 #pragma unroll
       for (int ch = 0; ch < 4; ch++) {
-        go[ch] = refs[ch] >= 0 && tn[ch] <= tf[ch] && tf[ch] >= RT_T_FLOOR && tn[ch] <= c.best_t;
+        go[ch] = ok[ch] && refs[ch] >= 0 && tn[ch] <= c.best_t;
         if (go[ch] && (near < 0 || tn[ch] < near_tn)) {
           near = ch;
           near_tn = tn[ch];
@@ -350,9 +374,9 @@ struct tree_search {
     }
   }
 
-  RT_DEV void finish(const scene_dev& sc, float& t_out, int& i_out, lane_counters& k) {
+  RT_DEV void finish(const scene_dev& sc, const scene_view& sv, float& t_out, int& i_out, lane_counters& k) {
     if (c.redo) {
-      hit_linear<COUNTED>(sc, o, d, t_out, i_out, k);
+      hit_linear<COUNTED>(sv.scan_sph, sc.n_spheres, o, d, t_out, i_out, k);
       return;
     }
     t_out = c.best_i >= 0 ? c.best_t : -1.0f;
