@@ -179,7 +179,7 @@ struct searcher {
 // Lanes of a wave that are ready for their path phase wait until this many of
 // them are (or until no lane is traversing); until then the wave keeps taking
 // traversal steps for the others.
-#define RT_PHASE_VOTE 24
+#define RT_PHASE_VOTE 52
 
 // Persistent lanes with phase voting.
 //

@@ -78,9 +78,7 @@ RT_DEV void hit_linear(const float4* sph, int n, f3 o, f3 d, float& t_out, int& 
   float best_t = -1.0f;
   int best_i = -1;
   RT_COUNT(k, sphere_tests, (uint32_t)n);
-#pragma unroll 4
-  for (int i = 0; i < n; i++) {
-    const float4 s = sph[i];
+  auto test = [&](const float4 s, int i) {
     float h, disc;
     sphere_disc(s.x, s.y, s.z, s.w, o, d, a, h, disc);
     if (disc >= 0.0f) {
@@ -99,7 +97,32 @@ RT_DEV void hit_linear(const float4* sph, int n, f3 o, f3 d, float& t_out, int& 
         }
       }
     }
+  };
+  // Groups of four records, the next group's loads issued before the current
+  // group is tested, so that the record latency hides behind the arithmetic.
+  const int last = n - 1;
+  float4 n0, n1, n2, n3;
+  if (n > 0) {
+    n0 = sph[0];
+    n1 = sph[min(1, last)];
+    n2 = sph[min(2, last)];
+    n3 = sph[min(3, last)];
   }
+  int i = 0;
+  for (; i + 4 <= n; i += 4) {
+    const float4 c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+    n0 = sph[min(i + 4, last)];
+    n1 = sph[min(i + 5, last)];
+    n2 = sph[min(i + 6, last)];
+    n3 = sph[min(i + 7, last)];
+    test(c0, i);
+    test(c1, i + 1);
+    test(c2, i + 2);
+    test(c3, i + 3);
+  }
+  if (i < n) test(n0, i);
+  if (i + 1 < n) test(n1, i + 1);
+  if (i + 2 < n) test(n2, i + 2);
   t_out = best_t;
   i_out = best_i;
 }
