@@ -10,7 +10,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-DEVICE_LIB = os.path.join(HERE, "libraytrace_amd.so")
+# RAYTRACE_AMD_LIB names another build of the same library (kernel tuning experiments).
+DEVICE_LIB = os.environ.get("RAYTRACE_AMD_LIB") or os.path.join(HERE, "libraytrace_amd.so")
 HOST_LIB = os.path.join(HERE, "librt_host.so")
 
 c_float3 = ctypes.c_float * 3

@@ -20,6 +20,10 @@ enum {
   SEARCH_LINEAR_LDS = 5
 };
 
+#ifndef RT_LINEAR_WAVES
+#define RT_LINEAR_WAVES 8
+#endif
+
 template <int SEARCH>
 struct search_traits {
   static constexpr bool tree = SEARCH >= SEARCH_TREE_LDS_RAY && SEARCH <= SEARCH_TREE_GLB_NODE;
@@ -30,6 +34,8 @@ struct search_traits {
   static constexpr int threads = waves * 64;
   static constexpr int stack = lds ? 16 : 32;      // entries per lane
   static constexpr int stack_words = !tree ? 0 : (lds ? stack * 64 : stack * 128);  // per wave
+  // Waves per SIMD the register allocation of the render kernel aims for.
+  static constexpr int render_waves_per_simd = tree ? 4 : RT_LINEAR_WAVES;
 };
 
 struct scene_counts {
@@ -199,7 +205,7 @@ struct searcher {
 // do not hold the wave until the slowest ray of the segment is done; they wait
 // only until enough lanes are ready to make the path phase worth issuing.
 template <int SEARCH, int RNG, bool COUNTED>
-__global__ __launch_bounds__(search_traits<SEARCH>::threads) void rt_render_kernel(const render_args A) {
+__global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARCH>::render_waves_per_simd) void rt_render_kernel(const render_args A) {
   const rt_params& P = A.p;
   const scene_dev& sc = A.sc;
   scene_view sv;

@@ -15,7 +15,7 @@ for line in out.splitlines():
         cur = re.sub(r"\(.*", "", cur).replace("void ", "")
         rows[cur] = {}
         continue
-    m = re.search(r"remark:\s+([A-Za-z][\w ]*): (\d+)", line)
+    m = re.search(r"remark:\s+([A-Za-z][\w ]*?)(?: \[[^\]]*\])?: (\d+)", line)
     if m and cur:
         rows[cur][m.group(1).strip()] = int(m.group(2))
 filt = sys.argv[1] if len(sys.argv) > 1 else ""
