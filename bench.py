@@ -38,6 +38,19 @@ CONFIGS = {
 }
 
 
+def measured_traffic(kernel, workload):
+    """HBM bytes per step from the committed counter passes (profiles/pmc_traffic.json, written by
+    tools/pmc_traffic.py from `rocprofv3 --pmc` runs of this same command), or None when that
+    workload has not been profiled.  Counters cannot be read from inside the timed run."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f).get(f"{kernel}|{workload}")
+    except (OSError, ValueError):
+        return None
+    return rec["hbm_bytes_per_step"] if rec else None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,14 +235,15 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         })
+        traffic = measured_traffic(kname, result["config"]["workload"])
         if args.config == "c4":
             result["roofline"] = {"bound": "hbm", "achieved": algo_bytes / (avg_kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": algo_bytes / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  "traffic": None, "kernel": kname, "kernel_ms": avg_kernel_ms,
+                                  "traffic": traffic, "kernel": kname, "kernel_ms": avg_kernel_ms,
                                   "valu_tflops": achieved_tflops, "valu_frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS}
         else:
             result["roofline"] = {"bound": "valu_fp32", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS,
-                                  "unit": "TFLOP/s", "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
+                                  "unit": "TFLOP/s", "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
                                   "kernel": kname, "kernel_ms": avg_kernel_ms,
                                   "algorithmic_gflop_per_launch": flops / 1e9}
         result["counters_per_launch"] = counters

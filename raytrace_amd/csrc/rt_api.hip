@@ -297,14 +297,22 @@ const char* search_name(int search, bool render) {
   }
 }
 
-// Ready lanes a wave waits for before it interrupts traversal for the path
-// phase (RT_PHASE_VOTE in the environment overrides the default, for tuning).
+// Ready lanes a wave waits for before it interrupts traversal for the other
+// phase: the path phase of the render kernels (long, so worth waiting for a
+// nearly full wave) and the fetch / store phase of the closest-hit kernel
+// (short).  RT_PHASE_VOTE / RT_TRACE_VOTE in the environment override the
+// defaults, for tuning.
+int vote_from_env(const char* name, int fallback) {
+  const char* e = getenv(name);
+  int x = e ? atoi(e) : fallback;
+  return x < 1 ? 1 : (x > 64 ? 64 : x);
+}
 int phase_vote() {
-  static int v = [] {
-    const char* e = getenv("RT_PHASE_VOTE");
-    int x = e ? atoi(e) : RT_PHASE_VOTE;
-    return x < 1 ? 1 : (x > 64 ? 64 : x);
-  }();
+  static int v = vote_from_env("RT_PHASE_VOTE", RT_PHASE_VOTE);
+  return v;
+}
+int trace_vote() {
+  static int v = vote_from_env("RT_TRACE_VOTE", RT_TRACE_VOTE);
   return v;
 }
 
@@ -758,7 +766,7 @@ int rt_trace_batch_device(rt_ctx* c, const float* o_xyz, const float* d_xyz, siz
   a.counters = nullptr;
   HIP_TRY(c->queue.resize(1));
   a.queue = c->queue.p;
-  a.vote = phase_vote();
+  a.vote = trace_vote();
   if (counted) {
     HIP_TRY(c->counters.resize(sizeof(rt_counters) / sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(rt_counters), c->stream));

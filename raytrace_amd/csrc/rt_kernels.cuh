@@ -21,7 +21,7 @@ enum {
 };
 
 #ifndef RT_LINEAR_WAVES
-#define RT_LINEAR_WAVES 8
+#define RT_LINEAR_WAVES 5
 #endif
 
 template <int SEARCH>
@@ -186,6 +186,7 @@ struct searcher {
 // them are (or until no lane is traversing); until then the wave keeps taking
 // traversal steps for the others.
 #define RT_PHASE_VOTE 52
+#define RT_TRACE_VOTE 16
 
 // Persistent lanes with phase voting.
 //
