@@ -112,13 +112,16 @@ typedef struct rt_counters {
   uint64_t unit_tries;     /* tries of the random_unit_vector rejection loop            */
   uint64_t disk_tries;     /* tries of the random_unit_disk rejection loop              */
   uint64_t limit_hits;     /* paths ended by the bounce limit                           */
-  /* SIMD occupancy of the two phases of the render / trace loops: how many
-   * times a wave issued the phase, and how many lanes took part in total
-   * (lanes / (64 * waves) = fraction of the wave doing useful work).          */
+  /* SIMD occupancy of the three phases of the render / trace loops (node
+   * step, path phase, leaf step): how many times a wave issued the phase,
+   * and how many lanes took part in total (lanes / (64 * waves) = fraction
+   * of the wave doing useful work).                                           */
   uint64_t trav_wave_steps;
   uint64_t trav_lane_steps;
   uint64_t path_wave_phases;
   uint64_t path_lane_phases;
+  uint64_t leaf_wave_steps;
+  uint64_t leaf_lane_steps;
 } rt_counters;
 
 typedef struct rt_ctx rt_ctx;

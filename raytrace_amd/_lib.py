@@ -40,7 +40,8 @@ class RtParams(ctypes.Structure):
 
 COUNTER_FIELDS = ["paths", "segments", "sphere_tests", "roots", "node_tests", "hits", "sky", "lambertian",
                   "metallic", "dialectric", "perlin", "unit_tries", "disk_tries", "limit_hits",
-                  "trav_wave_steps", "trav_lane_steps", "path_wave_phases", "path_lane_phases"]
+                  "trav_wave_steps", "trav_lane_steps", "path_wave_phases", "path_lane_phases",
+                  "leaf_wave_steps", "leaf_lane_steps"]
 
 
 class RtCounters(ctypes.Structure):

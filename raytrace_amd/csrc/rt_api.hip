@@ -315,6 +315,11 @@ int trace_vote() {
   static int v = vote_from_env("RT_TRACE_VOTE", RT_TRACE_VOTE);
   return v;
 }
+// Lanes with queued leaves a wave waits for before it takes a leaf step.
+int leaf_vote() {
+  static int v = vote_from_env("RT_LEAF_VOTE", RT_LEAF_VOTE);
+  return v;
+}
 
 // Samples per pixel of the cost-probe pass, and the switch for two-pass
 // rendering (RT_TWO_PASS=0 in the environment turns it off, for comparison).
@@ -443,6 +448,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   HIP_TRY(c->queue.resize(1));
   a.queue = reinterpret_cast<unsigned int*>(c->queue.p);
   a.vote = phase_vote();
+  a.leaf_vote = leaf_vote();
   if (p->rng_mode == RT_RNG_XORSHIFT_REF && p->seed_tex) {
     HIP_TRY(c->seed_tex.resize(n_px));
     HIP_TRY(hipMemcpyAsync(c->seed_tex.p, p->seed_tex, n_px * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
@@ -767,6 +773,7 @@ int rt_trace_batch_device(rt_ctx* c, const float* o_xyz, const float* d_xyz, siz
   HIP_TRY(c->queue.resize(1));
   a.queue = c->queue.p;
   a.vote = trace_vote();
+  a.leaf_vote = leaf_vote();
   if (counted) {
     HIP_TRY(c->counters.resize(sizeof(rt_counters) / sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(rt_counters), c->stream));

@@ -97,7 +97,7 @@ RT_DEV uint32_t counter_key(uint32_t seed, uint32_t pixel, uint32_t sample) {
 struct lane_counters {
   uint32_t paths, segments, sphere_tests, roots, node_tests, hits, sky;
   uint32_t lambertian, metallic, dialectric, perlin, unit_tries, disk_tries, limit_hits;
-  uint32_t trav_wave_steps, trav_lane_steps, path_wave_phases, path_lane_phases;
+  uint32_t trav_wave_steps, trav_lane_steps, path_wave_phases, path_lane_phases, leaf_wave_steps, leaf_lane_steps;
 };
 #define RT_COUNT(c, field, n) \
   do {                        \

@@ -70,6 +70,7 @@ struct render_args {
   unsigned long long* counters;  // sizeof(rt_counters)/8 words, or null
   unsigned int* queue;         // head of the pixel queue, zero at launch
   int vote;                    // ready lanes needed before a wave leaves traversal for the path phase
+  int leaf_vote;               // lanes with queued leaves needed before a wave takes a leaf step
   // Two-pass rendering (pixel queue ordered by measured cost):
   //   pass 0  everything in one launch, queue in tile order
   //   pass 1  probe: the first few samples of every pixel in tile order; leaves the pixel's
@@ -87,12 +88,12 @@ struct render_args {
 template <bool COUNTED>
 RT_DEV void flush_counters(unsigned long long* g, const lane_counters& k) {
   if (!COUNTED || g == nullptr) return;
-  const uint32_t v[18] = {k.paths,           k.segments,        k.sphere_tests,     k.roots,           k.node_tests,
+  const uint32_t v[20] = {k.paths,           k.segments,        k.sphere_tests,     k.roots,           k.node_tests,
                           k.hits,            k.sky,             k.lambertian,       k.metallic,        k.dialectric,
                           k.perlin,          k.unit_tries,      k.disk_tries,       k.limit_hits,      k.trav_wave_steps,
-                          k.trav_lane_steps, k.path_wave_phases, k.path_lane_phases};
+                          k.trav_lane_steps, k.path_wave_phases, k.path_lane_phases, k.leaf_wave_steps, k.leaf_lane_steps};
 #pragma unroll
-  for (int i = 0; i < 18; i++) {
+  for (int i = 0; i < 20; i++) {
     // sum over the wave first: one atomic per wave and counter
     unsigned long long s = v[i];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
@@ -172,11 +173,16 @@ struct searcher {
     ts.c.redo = true;  // finish() runs the scan
     return false;
   }
-  RT_DEV bool step(const scene_view& sv, uint32_t* stack_col, lane_counters& k) {
+  static constexpr bool leaf_steps = T::tree && !T::lds;  // leaves wait for a step of their own
+  RT_DEV bool node_ready() const { return T::tree && ts.node_ready(); }
+  RT_DEV bool has_leaf() const { return T::tree && ts.has_leaf(); }
+  RT_DEV bool active() const { return T::tree && ts.active(); }
+  RT_DEV void step_node(const scene_view& sv, uint32_t* stack_col, lane_counters& k) {
     trav_stack<T::lds> stk;
     stk.col = stack_col;
-    return ts.step(sv, stk, k);
+    ts.step_node(sv, stk, k);
   }
+  RT_DEV void step_leaf(const scene_view& sv, lane_counters& k) { ts.step_leaf(sv, k); }
   RT_DEV void finish(const scene_dev& sc, const scene_view& sv, float& t, int& idx, lane_counters& k) {
     ts.finish(sc, sv, t, idx, k);
   }
@@ -187,6 +193,21 @@ struct searcher {
 // traversal steps for the others.
 #define RT_PHASE_VOTE 52
 #define RT_TRACE_VOTE 16
+#define RT_LEAF_VOTE 16
+
+// Tuning builds (-DRT_SECTION_CLOCKS) time the sections of the render loop with the
+// shader clock, per wave, and the counted launch reports the sums in place of the
+// hits .. unit_tries counters: traversal step, hit branch, sky branch, sample / pixel
+// turnover, camera ray, segment set-up, whole loop.
+#ifdef RT_SECTION_CLOCKS
+#define RT_CLK_DECL unsigned long long clk_[7] = {0, 0, 0, 0, 0, 0, 0}; unsigned long long clk_t_ = 0, clk_0_ = __builtin_amdgcn_s_memtime();
+#define RT_CLK_START() clk_t_ = __builtin_amdgcn_s_memtime()
+#define RT_CLK_STOP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); clk_[i] += n_ - clk_t_; clk_t_ = n_; } while (0)
+#else
+#define RT_CLK_DECL
+#define RT_CLK_START() do {} while (0)
+#define RT_CLK_STOP(i) do {} while (0)
+#endif
 
 // Persistent lanes with phase voting.
 //
@@ -256,23 +277,34 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
     have = false;
   };
 
+  RT_CLK_DECL
   while (true) {
     const unsigned long long m_trav = __ballot(in_trav);
     const unsigned long long m_ready = __ballot(!in_trav && !exhausted);
     if ((m_trav | m_ready) == 0ull) break;
     const bool path_phase = m_trav == 0ull || __popcll(m_ready) >= A.vote;
-    if (!path_phase) {
-      RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
-      RT_COUNT(k, trav_lane_steps, in_trav ? 1u : 0u);
-      if (in_trav) in_trav = srch.step(sv, stack_col, k);  // `pending` (set at begin) marks the result as unread
+    RT_CLK_START();
+    if (!path_phase) {  // `pending` (set at begin) marks the result as unread
+      const bool node_lane = in_trav && srch.node_ready(), leaf_lane = in_trav && srch.has_leaf();
+      if (srch.leaf_steps && (__ballot(node_lane) == 0ull || __popcll(__ballot(leaf_lane)) >= A.leaf_vote)) {
+        RT_COUNT(k, leaf_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
+        RT_COUNT(k, leaf_lane_steps, leaf_lane ? 1u : 0u);
+        if (leaf_lane) srch.step_leaf(sv, k);
+      } else {
+        RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
+        RT_COUNT(k, trav_lane_steps, node_lane ? 1u : 0u);
+        if (node_lane) srch.step_node(sv, stack_col, k);
+      }
+      if (in_trav) in_trav = srch.active();
+      RT_CLK_STOP(0);
       continue;
     }
     RT_COUNT(k, path_wave_phases, (threadIdx.x & 63) == 0 ? 1u : 0u);
-    if (in_trav || exhausted) continue;  // only ready lanes take the path phase
-    RT_COUNT(k, path_lane_phases, 1);
+    const bool ready = !(in_trav || exhausted);  // only ready lanes take the path phase
+    RT_COUNT(k, path_lane_phases, ready ? 1u : 0u);
 
     bool start_segment = false;
-    if (pending) {  // the search for the current segment is over: bounce(), fs:207-219
+    if (ready && pending) {  // the search for the current segment is over: bounce(), fs:207-219
       pending = false;
       float t;
       int idx;
@@ -298,10 +330,12 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
         next_o = h.point;  // fs:211-212
         count = count + 1u;
         cont = shade_hit<RNG, COUNTED>(h, type, ma.w, mk3(ma.x, ma.y, ma.z), d, alb, rng, k);
+        RT_CLK_STOP(1);
       } else {  // fs:217-218
         alb = sky_radiance(d, alb);
         cont = false;
         RT_COUNT(k, sky, 1);
+        RT_CLK_STOP(2);
       }
       if (cont && count >= P.bounce_limit) {  // the next bounce() would stop here, fs:203-205
         alb = mk3(0.0f, 0.0f, 0.0f);
@@ -319,7 +353,8 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
         if (s >= P.sample_end) close_pixel();
       }
     }
-    if (!start_segment) {
+    RT_CLK_STOP(3);
+    if (ready && !start_segment) {
       if (!have) {  // pull the next pixel
         const uint32_t item = atomicAdd(A.queue, 1u);
         if (item >= total_items) {
@@ -355,6 +390,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
           }
         }
       }
+      RT_CLK_STOP(3);
       if (have && !alive) {  // fs:117-131: next camera sample of this pixel
         if (RNG == RT_RNG_COUNTER) rng = counter_key(P.seed, pixel, (uint32_t)s);
         const float jx = rng_float<RNG>(rng) - 0.5f;
@@ -383,13 +419,22 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
         }
       }
     }
+    RT_CLK_STOP(4);
     if (start_segment) {
       RT_COUNT(k, segments, 1);
       pixel_segments++;
       in_trav = srch.begin(sc, sv, srch.ts.o, srch.ts.d, k);
       pending = true;
     }
+    RT_CLK_STOP(5);
   }
+#ifdef RT_SECTION_CLOCKS
+  if (COUNTED && A.counters != nullptr && (threadIdx.x & 63) == 0) {
+    clk_[6] = __builtin_amdgcn_s_memtime() - clk_0_;
+    for (int i = 0; i < 7; i++) atomicAdd(A.counters + 5 + i, clk_[i]);
+  }
+  k.hits = k.sky = k.lambertian = k.metallic = k.dialectric = k.perlin = k.unit_tries = 0;
+#endif
   flush_counters<COUNTED>(A.counters, k);
 }
 
@@ -404,6 +449,7 @@ struct trace_args {
   unsigned long long* counters;
   unsigned long long* queue;  // next ray index, zero at launch
   int vote;
+  int leaf_vote;
 };
 
 // hit_any (fs:165-199) for a batch of rays: persistent lanes pull ray indices
@@ -426,9 +472,17 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads) void rt_trace_kerne
     if ((m_trav | m_ready) == 0ull) break;
     const bool path_phase = m_trav == 0ull || __popcll(m_ready) >= A.vote;
     if (!path_phase) {
-      RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
-      RT_COUNT(k, trav_lane_steps, in_trav ? 1u : 0u);
-      if (in_trav) in_trav = srch.step(sv, stack_col, k);
+      const bool node_lane = in_trav && srch.node_ready(), leaf_lane = in_trav && srch.has_leaf();
+      if (srch.leaf_steps && (__ballot(node_lane) == 0ull || __popcll(__ballot(leaf_lane)) >= A.leaf_vote)) {
+        RT_COUNT(k, leaf_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
+        RT_COUNT(k, leaf_lane_steps, leaf_lane ? 1u : 0u);
+        if (leaf_lane) srch.step_leaf(sv, k);
+      } else {
+        RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
+        RT_COUNT(k, trav_lane_steps, node_lane ? 1u : 0u);
+        if (node_lane) srch.step_node(sv, stack_col, k);
+      }
+      if (in_trav) in_trav = srch.active();
       continue;
     }
     RT_COUNT(k, path_wave_phases, (threadIdx.x & 63) == 0 ? 1u : 0u);

@@ -244,20 +244,71 @@ struct trav_stack<false> {
   uint32_t* col;  // refs at col[e * 128], entry parameters at col[e * 128 + 64]
 };
 
+// Leaves whose box a node step found worth testing wait here until the wave
+// takes a leaf step: six Morton positions (stored +1, zero = empty slot) per
+// lane, 10 bits each in one word when the tree is the LDS-resident kind (at
+// most 1022 leaves), 32 bits each in three words otherwise.
+template <bool PACKED>
+struct leaf_queue;
+
+template <>
+struct leaf_queue<true> {
+  static constexpr int max_leaves = 1022;
+  unsigned long long q;
+  RT_DEV void clear() { q = 0ull; }
+  RT_DEV bool empty() const { return q == 0ull; }
+  RT_DEV bool room_for_node() const { return (q >> 20) == 0ull; }  // at most two waiting: four more fit
+  RT_DEV void push(int pos) { q = (q << 10) | (unsigned long long)(pos + 1); }
+  RT_DEV int pop() {
+    const int pos = (int)(q & 1023ull) - 1;
+    q >>= 10;
+    return pos;
+  }
+};
+
+template <>
+struct leaf_queue<false> {
+  unsigned long long a, b, c;  // two 32-bit entries each, a the newest pair
+  RT_DEV void clear() { a = b = c = 0ull; }
+  RT_DEV bool empty() const { return a == 0ull; }
+  RT_DEV bool room_for_node() const { return (b | c) == 0ull; }
+  RT_DEV void push(int pos) {
+    c = (c << 32) | (b >> 32);
+    b = (b << 32) | (a >> 32);
+    a = (a << 32) | (unsigned long long)(uint32_t)(pos + 1);
+  }
+  RT_DEV int pop() {
+    const int pos = (int)(uint32_t)a - 1;
+    a = (a >> 32) | (b << 32);
+    b = (b >> 32) | (c << 32);
+    c >>= 32;
+    return pos;
+  }
+};
+
 // A closest-hit search that can be advanced one node at a time, so that a wave
 // can interleave the traversal steps of some lanes with other work of others.
 //   begin()  exact tests of the spheres kept out of the tree, per-ray constants;
 //            returns true when step() must be called
-//   step()   one 4-wide node: four box tests, exact tests of the leaves among
-//            them, ordered descent; returns false when the search is over
-//   finish() the scan's answer (repeats the ray with the scan when flagged)
+//   step_node()  one 4-wide node: four box tests, leaves among the children
+//                queued, ordered descent
+//   step_leaf()  exact test of one queued leaf
+//   active()     false when the search is over
+//   finish()     the scan's answer (repeats the ray with the scan when flagged)
 template <bool PAD_RAY, bool PACKED, int STACK, bool COUNTED>
 struct tree_search {
   f3 o, d;
   float a;
   slab_consts sl;
   trav_candidate c;
-  int cur, sp;
+  int cur, sp;  // cur: node to test next, -1 when the stack has run dry
+  static constexpr bool LEAF_INLINE = PACKED;
+  leaf_queue<PACKED> lq;
+
+  RT_DEV bool has_node() const { return cur >= 0; }
+  RT_DEV bool node_ready() const { return cur >= 0 && (LEAF_INLINE || lq.room_for_node()); }
+  RT_DEV bool has_leaf() const { return !LEAF_INLINE && !lq.empty(); }
+  RT_DEV bool active() const { return cur >= 0 || has_leaf(); }
 
   RT_DEV bool begin(const scene_dev& sc, const scene_view& sv, f3 origin, f3 dir, lane_counters& k) {
     o = origin;
@@ -267,6 +318,8 @@ struct tree_search {
     c.best_i = -1;
     c.redo = false;
     sp = 0;
+    cur = -1;
+    if (!LEAF_INLINE) lq.clear();
     if (!(a > 0.0f) || !(a < __builtin_inff())) {  // zero, NaN or overflowing direction: the scan decides
       c.redo = true;
       return false;
@@ -280,15 +333,20 @@ struct tree_search {
     sl.inv_d = mk3(__builtin_amdgcn_rcpf(slab_dir(d.x)), __builtin_amdgcn_rcpf(slab_dir(d.y)),
                    __builtin_amdgcn_rcpf(slab_dir(d.z)));
     if (PAD_RAY) make_slab_consts(sc, o, sl.inv_d, a, c, sl);
-    cur = sc.root;
-    if (cur < 0) {  // a single sphere in the tree
-      consider_sphere<COUNTED>(sv.leaf_sph[~cur], sv.leaf_idx[~cur], o, d, a, c, k);
+    if (sc.root < 0) {  // a single sphere in the tree
+      consider_sphere<COUNTED>(sv.leaf_sph[~sc.root], sv.leaf_idx[~sc.root], o, d, a, c, k);
       return false;
     }
+    cur = sc.root;
     return true;
   }
 
-  RT_DEV bool step(const scene_view& sv, trav_stack<PACKED> stk, lane_counters& k) {
+  RT_DEV void step_leaf(const scene_view& sv, lane_counters& k) {
+    const int pos = lq.pop();
+    consider_sphere<COUNTED>(sv.leaf_sph[pos], sv.leaf_idx[pos], o, d, a, c, k);
+  }
+
+  RT_DEV void step_node(const scene_view& sv, trav_stack<PACKED> stk, lane_counters& k) {
     const bvh4_node* nd = sv.nodes + cur;
     const float4 lox = reinterpret_cast<const float4*>(nd)[0];
     const float4 loy = reinterpret_cast<const float4*>(nd)[1];
@@ -309,10 +367,16 @@ struct tree_search {
     for (int ch = 0; ch < 4; ch++) {
       ok[ch] = tn[ch] <= tf[ch] && refs[ch] != RT_REF_EMPTY;
       RT_COUNT(k, node_tests, refs[ch] != RT_REF_EMPTY ? 1u : 0u);
-      if (ok[ch] && refs[ch] < 0) leaf_mask |= 1u << ch;
+      if (ok[ch] && refs[ch] < 0) {
+        if (LEAF_INLINE) leaf_mask |= 1u << ch;
+        else lq.push(~refs[ch]);
+      }
     }
-    // leaves first: an exact hit shortens the ray for the boxes below
-    while (leaf_mask) {
+    // LDS-resident scenes test the leaves here and now (an exact hit shortens the
+    // ray for the boxes below, and a leaf costs less than another trip round the
+    // wave's loop); scenes read from HBM queue them for a leaf step, so that the
+    // wave waits for leaf records once per step, not once per node
+    while (LEAF_INLINE && leaf_mask) {
       const int ch = __builtin_ctz(leaf_mask);
       leaf_mask &= leaf_mask - 1;
       const int r = ch == 0 ? refs[0] : ch == 1 ? refs[1] : ch == 2 ? refs[2] : refs[3];
@@ -346,17 +410,17 @@ struct tree_search {
       }
       if (key[0] != 0xFFFFFFFFu) {
         cur = trav_stack<true>::key_ref(key[0]);
-        return true;
+        return;
       }
+      cur = -1;
       while (sp > 0) {
         sp--;
         const uint32_t e = stk.col[sp * 64];
         if (trav_stack<true>::key_tn(e) <= c.best_t) {
           cur = trav_stack<true>::key_ref(e);
-          return true;
+          return;
         }
       }
-      return false;
     } else {
       // nearest child continues, the others are pushed with their entry parameter
       int near = -1;
@@ -384,16 +448,16 @@ struct tree_search {
       }
       if (near >= 0) {
         cur = near == 0 ? refs[0] : near == 1 ? refs[1] : near == 2 ? refs[2] : refs[3];
-        return true;
+        return;
       }
+      cur = -1;
       while (sp > 0) {
         sp--;
         if (__uint_as_float(stk.col[sp * 128 + 64]) <= c.best_t) {
           cur = (int)stk.col[sp * 128];
-          return true;
+          return;
         }
       }
-      return false;
     }
   }
 

@@ -35,7 +35,7 @@ def test_host_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_lib.RtParams) == 136
     assert _lib.RtParams.delta_u.offset == 40 and _lib.RtParams.seed_tex.offset == 128
-    assert ctypes.sizeof(_lib.RtCounters) == 18 * 8
+    assert ctypes.sizeof(_lib.RtCounters) == 20 * 8
     assert ctypes.sizeof(_lib.RtCamera) == 52
 
 
