@@ -112,6 +112,7 @@ struct rt_ctx {
 
   dev_buf<uint32_t> seed_tex;
   dev_buf<unsigned long long> queue;  // work-queue head of the running launch
+  dev_buf<uint32_t> ovf;              // traversal-stack overflow of the running launch (HBM-resident trees)
   // two-pass rendering: per-pixel carry of the probe pass and the sorted pixel order
   dev_buf<float> carry_colour;
   dev_buf<uint32_t> carry_rng, carry_key, carry_idx, order_key, order_idx;
@@ -146,6 +147,8 @@ struct rt_ctx {
     }
     s.r_max = r_max;
     s.abs_max = abs_max;
+    s.ovf = nullptr;
+    s.ovf_cap = 0;
     return s;
   }
 };
@@ -360,8 +363,24 @@ hipError_t allow_lds(K kernel, size_t bytes) {
 
 // Persistent launch: as many workgroups as the chip keeps resident (fewer when
 // the image has fewer 8x8 tiles than that).
+// Stack entries a lane of an HBM-resident tree may need beyond its LDS part:
+// a node step pushes at most three children and the 4-wide tree has
+// depth / 2 + 1 levels.
+template <int SEARCH>
+hipError_t attach_overflow(rt_ctx* c, long long blocks, scene_dev& sc) {
+  using T = search_traits<SEARCH>;
+  if (!T::tree || T::lds) return hipSuccess;
+  const int cap = 3 * (c->depth / 2 + 2) - T::stack;
+  if (cap <= 0) return hipSuccess;
+  hipError_t e = c->ovf.resize((size_t)blocks * T::waves * (size_t)cap * 128);
+  if (e != hipSuccess) return e;
+  sc.ovf = c->ovf.p;
+  sc.ovf_cap = cap;
+  return hipSuccess;
+}
+
 template <int SEARCH, int RNG, bool COUNTED>
-hipError_t launch_render_one(const rt_ctx* c, const rt_params* p, hipStream_t st, const render_args& a) {
+hipError_t launch_render_one(rt_ctx* c, const rt_params* p, hipStream_t st, render_args a) {
   using T = search_traits<SEARCH>;
   const int tw = p->tile_x1 - p->tile_x0, th = p->tile_y1 - p->tile_y0;
   const size_t lds = search_lds_bytes<SEARCH>(counts_of(c));
@@ -376,12 +395,14 @@ hipError_t launch_render_one(const rt_ctx* c, const rt_params* p, hipStream_t st
   const long long needed = (tiles + T::waves - 1) / T::waves;
   if (blocks > needed) blocks = needed;
   if (blocks < 1) blocks = 1;
+  e = attach_overflow<SEARCH>(c, blocks, a.sc);
+  if (e != hipSuccess) return e;
   rt_render_kernel<SEARCH, RNG, COUNTED><<<dim3((unsigned)blocks), T::threads, lds, st>>>(a);
   return hipGetLastError();
 }
 
 template <int SEARCH>
-hipError_t launch_render(const rt_ctx* c, const rt_params* p, bool counted, hipStream_t st, const render_args& a) {
+hipError_t launch_render(rt_ctx* c, const rt_params* p, bool counted, hipStream_t st, const render_args& a) {
   if (p->rng_mode == RT_RNG_XORSHIFT_REF)
     return counted ? launch_render_one<SEARCH, RT_RNG_XORSHIFT_REF, true>(c, p, st, a)
                    : launch_render_one<SEARCH, RT_RNG_XORSHIFT_REF, false>(c, p, st, a);
@@ -390,7 +411,7 @@ hipError_t launch_render(const rt_ctx* c, const rt_params* p, bool counted, hipS
 }
 
 template <int SEARCH, bool COUNTED>
-hipError_t launch_trace_one(const rt_ctx* c, hipStream_t st, const trace_args& a) {
+hipError_t launch_trace_one(rt_ctx* c, hipStream_t st, trace_args a) {
   using T = search_traits<SEARCH>;
   const size_t lds = search_lds_bytes<SEARCH>(counts_of(c));
   hipError_t e = allow_lds(rt_trace_kernel<SEARCH, COUNTED>, lds);
@@ -403,12 +424,14 @@ hipError_t launch_trace_one(const rt_ctx* c, hipStream_t st, const trace_args& a
   const long long needed = (long long)((a.n + T::threads - 1) / T::threads);
   if (blocks > needed) blocks = needed;
   if (blocks < 1) blocks = 1;
+  e = attach_overflow<SEARCH>(c, blocks, a.sc);
+  if (e != hipSuccess) return e;
   rt_trace_kernel<SEARCH, COUNTED><<<dim3((unsigned)blocks), T::threads, lds, st>>>(a);
   return hipGetLastError();
 }
 
 template <int SEARCH>
-hipError_t launch_trace(const rt_ctx* c, bool counted, hipStream_t st, const trace_args& a) {
+hipError_t launch_trace(rt_ctx* c, bool counted, hipStream_t st, const trace_args& a) {
   return counted ? launch_trace_one<SEARCH, true>(c, st, a) : launch_trace_one<SEARCH, false>(c, st, a);
 }
 
@@ -574,7 +597,7 @@ void rt_destroy(rt_ctx* c) {
   c->sph.release(); c->inv_r.release(); c->sph_mat.release(); c->mat_type.release(); c->mat_a.release();
   c->big_sph.release(); c->big_idx.release(); c->tree_sph.release(); c->tree_r.release(); c->tree_orig.release();
   c->nodes.release(); c->leaf_sph.release(); c->leaf_r.release(); c->leaf_idx.release();
-  c->accum_own.release(); c->seed_tex.release(); c->queue.release(); c->counters.release();
+  c->accum_own.release(); c->seed_tex.release(); c->queue.release(); c->counters.release(); c->ovf.release();
   c->carry_colour.release(); c->carry_rng.release(); c->carry_key.release(); c->carry_idx.release();
   c->order_key.release(); c->order_idx.release(); c->sort_temp.release(); c->out_linear.release(); c->out_rgb8.release();
   if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);

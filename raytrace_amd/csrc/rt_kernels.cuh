@@ -20,6 +20,9 @@ enum {
   SEARCH_LINEAR_LDS = 5
 };
 
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 5
+#endif
 #ifndef RT_LINEAR_WAVES
 #define RT_LINEAR_WAVES 5
 #endif
@@ -32,10 +35,12 @@ struct search_traits {
   static constexpr bool pad_ray = SEARCH == SEARCH_TREE_LDS_RAY || SEARCH == SEARCH_TREE_GLB_RAY;
   static constexpr int waves = lds ? 16 : 4;       // waves per workgroup
   static constexpr int threads = waves * 64;
-  static constexpr int stack = lds ? 16 : 32;      // entries per lane
+  static constexpr int stack = lds ? 16 : 8;       // entries per lane kept in LDS
   static constexpr int stack_words = !tree ? 0 : (lds ? stack * 64 : stack * 128);  // per wave
   // Waves per SIMD the register allocation of the render kernel aims for.
   static constexpr int render_waves_per_simd = tree ? 4 : RT_LINEAR_WAVES;
+  // The closest-hit kernel on an HBM-resident tree waits on node fetches: more waves hide more of them.
+  static constexpr int trace_waves_per_simd = (tree && !lds) ? RT_TRACE_WAVES : 4;
 };
 
 struct scene_counts {
@@ -121,6 +126,8 @@ RT_DEV void search_setup(const scene_dev& sc, scene_view& sv, uint32_t*& stack_c
   sv.sph_mat = sc.sph_mat;
   sv.mat_a = sc.mat_a;
   sv.mat_type = sc.mat_type;
+  sv.ovf_col = nullptr;
+  sv.ovf_cap = 0;
   stack_col = nullptr;
   unsigned char* base = rt_lds;
   if (T::scan_lds) {
@@ -158,6 +165,10 @@ RT_DEV void search_setup(const scene_dev& sc, scene_view& sv, uint32_t*& stack_c
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   stack_col = reinterpret_cast<uint32_t*>(base) + wave * T::stack_words + lane;
+  if (!T::lds && sc.ovf != nullptr) {
+    sv.ovf_col = sc.ovf + ((size_t)blockIdx.x * T::waves + wave) * (size_t)sc.ovf_cap * 128 + lane;
+    sv.ovf_cap = sc.ovf_cap;
+  }
 }
 
 // The search object of a kernel: the stepwise tree search, or for the linear
@@ -194,6 +205,37 @@ struct searcher {
 #define RT_PHASE_VOTE 52
 #define RT_TRACE_VOTE 16
 #define RT_LEAF_VOTE 16
+
+// Work items (pixels, rays) come from one global counter.  Same-address atomics
+// from the whole chip complete at roughly 80 million per second, so a wave takes
+// a chunk per atomic and hands the items of its chunk to its lanes by ballot
+// rank.  `need` marks the lanes that want an item; every lane of the wave must
+// call this together.  Returns the lane's item (any value for lanes that did
+// not ask); items at or beyond the total mean the queue is dry.
+template <typename Q, uint32_t CHUNK>
+RT_DEV Q take_items(bool need, Q* queue, Q& pool_next, Q& pool_end) {
+  const unsigned long long m_need = __ballot(need);
+  Q item = 0;
+  if (m_need != 0ull) {
+    const uint32_t n_need = (uint32_t)__popcll(m_need);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_need, 0u));
+    const Q avail = pool_end - pool_next;
+    if (avail < (Q)n_need) {
+      Q fresh = 0;
+      if ((threadIdx.x & 63) == 0) fresh = atomicAdd(queue, (Q)CHUNK);
+      fresh = sizeof(Q) == 8 ? (Q)(((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)((unsigned long long)fresh >> 32)) << 32) |
+                                   __builtin_amdgcn_readfirstlane((uint32_t)fresh))
+                             : (Q)__builtin_amdgcn_readfirstlane((uint32_t)fresh);
+      item = (Q)rank < avail ? pool_next + rank : fresh + ((Q)rank - avail);
+      pool_next = fresh + ((Q)n_need - avail);
+      pool_end = fresh + (Q)CHUNK;
+    } else {
+      item = pool_next + rank;
+      pool_next += (Q)n_need;
+    }
+  }
+  return item;
+}
 
 // Tuning builds (-DRT_SECTION_CLOCKS) time the sections of the render loop with the
 // shader clock, per wave, and the counted launch reports the sums in place of the
@@ -256,6 +298,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
   uint32_t pixel = 0, rect_pixel = 0, rng = 0, count = 0, pixel_segments = 0;
   f3 colour = mk3(0.0f, 0.0f, 0.0f);
   f3 alb = colour;
+  uint32_t pool_next = 0, pool_end = 0;  // the wave's share of the pixel queue
 
   // The pixel's sample range is over: pass 0 / 2 add its sum to the image, the
   // probe pass parks it (with the RNG state and a cost key) for pass 2.
@@ -354,9 +397,10 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       }
     }
     RT_CLK_STOP(3);
+    const bool need_pixel = ready && !start_segment && !have;
+    const uint32_t item = take_items<unsigned int, 64u>(need_pixel, A.queue, pool_next, pool_end);
     if (ready && !start_segment) {
-      if (!have) {  // pull the next pixel
-        const uint32_t item = atomicAdd(A.queue, 1u);
+      if (!have) {  // the next pixel
         if (item >= total_items) {
           exhausted = true;
         } else {
@@ -456,7 +500,7 @@ struct trace_args {
 // from a queue, with the same phase voting as the renderer (a lane that has
 // finished its ray fetches the next one while others keep traversing).
 template <int SEARCH, bool COUNTED>
-__global__ __launch_bounds__(search_traits<SEARCH>::threads) void rt_trace_kernel(const trace_args A) {
+__global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARCH>::trace_waves_per_simd) void rt_trace_kernel(const trace_args A) {
   const scene_dev& sc = A.sc;
   scene_view sv;
   uint32_t* stack_col;
@@ -465,6 +509,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads) void rt_trace_kerne
   searcher<SEARCH, COUNTED> srch;
   bool pending = false, in_trav = false, exhausted = false;
   size_t ray = 0;
+  unsigned long long pool_next = 0, pool_end = 0;  // the wave's share of the ray queue
 
   while (true) {
     const unsigned long long m_trav = __ballot(in_trav);
@@ -486,7 +531,9 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads) void rt_trace_kerne
       continue;
     }
     RT_COUNT(k, path_wave_phases, (threadIdx.x & 63) == 0 ? 1u : 0u);
-    if (in_trav || exhausted) continue;
+    const bool ready = !(in_trav || exhausted);
+    const unsigned long long next_ray = take_items<unsigned long long, 256u>(ready, A.queue, pool_next, pool_end);
+    if (!ready) continue;
     RT_COUNT(k, path_lane_phases, 1);
     if (pending) {
       pending = false;
@@ -512,7 +559,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads) void rt_trace_kerne
       A.nrm[3 * ray + 1] = n.y;
       A.nrm[3 * ray + 2] = n.z;
     }
-    ray = (size_t)atomicAdd(A.queue, 1ull);
+    ray = (size_t)next_ray;
     if (ray >= A.n) {
       exhausted = true;
     } else {

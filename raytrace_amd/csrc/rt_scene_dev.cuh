@@ -40,6 +40,11 @@ struct scene_dev {
   float root_lo[3], root_hi[3];  // bounds of the tree's spheres
   float r_max;              // largest radius in the tree
   float abs_max;            // largest |coordinate| sum of the root box corners
+  // Trees read from HBM keep only the top of each lane's traversal stack in
+  // LDS; deeper entries go to this per-launch buffer (ovf_cap entries per lane,
+  // sized from the tree's depth so that a push can never fail).
+  uint32_t* ovf;
+  int32_t ovf_cap;
 };
 
 // The arrays a kernel actually reads: the HBM originals or their LDS copies.
@@ -54,6 +59,8 @@ struct scene_view {
   const int32_t* sph_mat;
   const float4* mat_a;
   const int32_t* mat_type;
+  uint32_t* ovf_col;        // this lane's column of the stack overflow buffer: entry e at ovf_col[e * 128] (+64: parameter)
+  int32_t ovf_cap;
 };
 
 // ---------------------------------------------------------------------------
@@ -441,6 +448,10 @@ struct tree_search {
             stk.col[sp * 128] = (uint32_t)refs[ch];
             stk.col[sp * 128 + 64] = __float_as_uint(tn[ch]);
             sp++;
+          } else if (sp - STACK < sv.ovf_cap) {
+            sv.ovf_col[(size_t)(sp - STACK) * 128] = (uint32_t)refs[ch];
+            sv.ovf_col[(size_t)(sp - STACK) * 128 + 64] = __float_as_uint(tn[ch]);
+            sp++;
           } else {
             c.redo = true;
           }
@@ -453,8 +464,9 @@ struct tree_search {
       cur = -1;
       while (sp > 0) {
         sp--;
-        if (__uint_as_float(stk.col[sp * 128 + 64]) <= c.best_t) {
-          cur = (int)stk.col[sp * 128];
+        const uint32_t* e = sp < STACK ? stk.col + sp * 128 : sv.ovf_col + (size_t)(sp - STACK) * 128;
+        if (__uint_as_float(e[64]) <= c.best_t) {
+          cur = (int)e[0];
           return;
         }
       }
