@@ -257,6 +257,18 @@ RT_API int rt_last_build_ms(rt_ctx* ctx, float* ms);
  * leaf; it sizes the traversal stack).  0 for the linear scan. */
 RT_API int rt_lbvh_depth(rt_ctx* ctx);
 
+/* The seed image of the reference, ready for rt_params.seed_tex: what
+ * shaders/perlin.fs draws into an RGB8 texture (raytrace.cpp:309-328; the
+ * reference calls it with GRID_SIZE 400, CONTRAST 1.5, LAYERS 12 and, through
+ * the slip at :326, LACURNITY 1.5) as the ray shader reads it back
+ * (testFragment.fs:105-106: the bits of r+g+b of the texel under the pixel,
+ * rows flipped because the ray shader counts rows from the top).  GLSL leaves
+ * the precision of sin() to the driver, so no two GL devices agree on this
+ * image; here sin is the double-precision sine rounded to binary32.
+ * seed_tex: width*height words, host memory.                                 */
+RT_API int rt_seed_texture(rt_ctx* ctx, int width, int height, float grid_size, float contrast, int layers,
+                           float lacunarity, uint32_t* seed_tex);
+
 /* Number of HIP devices visible (0 if none or the runtime cannot start). */
 RT_API int rt_device_count(void);
 

@@ -56,6 +56,9 @@ def lib():
         L.orc_refract.restype = None
         L.orc_refract.argtypes = [f3, f3, ctypes.c_float, f3]
         L.orc_perlin.restype = ctypes.c_float
+        L.orc_seed_texture.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,
+                                       ctypes.c_float, ctypes.c_void_p]
+        L.orc_seed_texture.restype = None
         L.orc_perlin.argtypes = [ctypes.c_float, ctypes.c_float]
         L.orc_perlin_gradient.restype = None
         L.orc_perlin_gradient.argtypes = [ctypes.c_int, ctypes.c_int, f3]
@@ -114,3 +117,11 @@ def shade_sky(direction, albedo):
     out = (ctypes.c_float * 3)()
     lib().orc_shade_sky(_vec(direction), _vec(albedo), out)
     return [float(x) for x in out]
+
+
+def seed_texture(width, height, grid=400.0, contrast=1.5, layers=12, lacunarity=1.5):
+    """The per-pixel seed words the ray shader reads from the perlin.fs image (defaults: raytrace.cpp:316-326,
+    where LACURNITY is set from PERLIN_CONTRAST, i.e. 1.5)."""
+    out = np.zeros((height, width), dtype=np.uint32)
+    lib().orc_seed_texture(width, height, grid, contrast, layers, lacunarity, out.ctypes.data)
+    return out

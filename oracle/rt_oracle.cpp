@@ -628,6 +628,76 @@ void orc_refract(const float* i, const float* n, float eta, float* out) {
   V3 r = refract(ld3(i), ld3(n), eta);
   out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
+// ---------------------------------------------------------------------------
+// The seed image: shaders/perlin.fs drawn into an RGB8 texture
+// (raytrace.cpp:309-328, 566-579) and read back by the ray shader (fs:105-106).
+// GLSL leaves sin() to the driver; this restatement takes it as the double
+// sine rounded to binary32.  fract(x) = x - floor(x).
+namespace seedtex {
+float interpolate(float a0, float a1, float w) {  // perlin.fs:44-46
+  return (a1 - a0) * (3.0f - w * 2.0f) * w * w + a0;
+}
+float glsl_sin(float x) { return (float)std::sin((double)x); }
+float fract(float x) { return x - std::floor(x); }
+void random_gradient(int ix, int iy, float& gx, float& gy) {  // perlin.fs:48-53
+  const float ux = (float)ix, uy = (float)iy;                 // :49
+  const float a = ux * 127.1f + uy * 311.7f;                  // :50
+  const float b = ux * 269.5f + uy * 183.3f;                  // :51
+  gx = -1.0f + 2.0f * fract(glsl_sin(a) * 43758.5453123f);    // :52
+  gy = -1.0f + 2.0f * fract(glsl_sin(b) * 43758.5453123f);
+}
+float dot_grid_gradient(int ix, int iy, float x, float y) {  // perlin.fs:55-62
+  float gx, gy;
+  random_gradient(ix, iy, gx, gy);
+  const float dx = x - (float)ix;
+  const float dy = y - (float)iy;
+  return dx * gx + dy * gy;
+}
+float perlin(float x, float y) {  // perlin.fs:64-87
+  const int x0 = (int)std::floor(x), x1 = x0 + 1;
+  const int y0 = (int)std::floor(y), y1 = y0 + 1;
+  const float sx = x - (float)x0, sy = y - (float)y0;
+  float n0 = dot_grid_gradient(x0, y0, x, y);
+  float n1 = dot_grid_gradient(x1, y0, x, y);
+  const float ix0 = interpolate(n0, n1, sx);
+  n0 = dot_grid_gradient(x0, y1, x, y);
+  n1 = dot_grid_gradient(x1, y1, x, y);
+  const float ix1 = interpolate(n0, n1, sx);
+  return interpolate(ix0, ix1, sy);
+}
+// perlin.fs:15-42 for the fragment whose window coordinates are (fx, fy).
+float fragment_value(float fx, float fy, float grid, float contrast, int layers, float lacunarity) {
+  float value = 0.0f, freq = 1.0f, amp = 1.0f;
+  for (int i = 0; i < layers; i++) {
+    value += perlin(fx * freq / grid, fy * freq / grid) * amp;  // :22
+    freq *= lacunarity;                                          // :24
+    amp /= 2.0f;                                                 // :25
+  }
+  value = value * contrast;          // :28
+  if (value > 1.0f) value = 1.0f;    // :30-32
+  if (value < -1.0f) value = -1.0f;  // :33-35
+  return value * 0.5f + 0.5f;        // :37
+}
+}  // namespace seedtex
+
+// seed_tex[y * width + x] for the ray shader's pixel (x, y), origin upper left
+// (fs:3): the bits of tex.r + tex.g + tex.b (fs:106) of texel (x, height-1-y) of
+// the RGB8 image perlin.fs draws with the window origin lower left.  The stored
+// channel is round(255 v), the sampled one c / 255.
+void orc_seed_texture(int width, int height, float grid, float contrast, int layers, float lacunarity, uint32_t* out) {
+  for (int y = 0; y < height; y++) {
+    const int ty = height - 1 - y;
+    for (int x = 0; x < width; x++) {
+      const float v = seedtex::fragment_value((float)x + 0.5f, (float)ty + 0.5f, grid, contrast, layers, lacunarity);
+      const float c = std::floor(v * 255.0f + 0.5f) / 255.0f;
+      const float sum = (c + c) + c;
+      uint32_t bits;
+      std::memcpy(&bits, &sum, 4);
+      out[(size_t)y * width + x] = bits;
+    }
+  }
+}
+
 float orc_perlin(float x, float y) { return perlin2(x, y); }
 void orc_perlin_gradient(int ix, int iy, float* g) { p_gradient(ix, iy, g[0], g[1]); }
 

@@ -192,6 +192,12 @@ class Renderer:
     def lbvh_depth(self):
         return int(self.lib.rt_lbvh_depth(self.ctx))
 
+    def seed_texture(self, width, height, grid=400.0, contrast=1.5, layers=12, lacunarity=1.5):
+        """The reference's seed image (perlin.fs pass, raytrace.cpp:309-328) as rt_params.seed_tex words."""
+        out = np.zeros((height, width), dtype=np.uint32)
+        self._check(self.lib.rt_seed_texture(self.ctx, width, height, grid, contrast, layers, lacunarity, out.ctypes.data))
+        return out
+
 
 # Algorithmic FP32 work per event (add/sub/mul/div/sqrt/min count 1 each; no
 # compares, no integer work): the flop model every roofline figure here uses.

@@ -67,7 +67,7 @@ DEVICE_SYMBOLS = [
     "rt_gl_buffer_bytes", "rt_gl_reset", "rt_gl_dropped_writes", "rt_scene_upload", "rt_render", "rt_render_counted",
     "rt_clear", "rt_set_accumulator", "rt_set_accumulated_samples", "rt_readback", "rt_trace_batch",
     "rt_trace_batch_device", "rt_synchronize", "rt_get_counters", "rt_last_kernel_ms", "rt_last_build_ms",
-    "rt_lbvh_depth", "rt_device_count",
+    "rt_lbvh_depth", "rt_device_count", "rt_seed_texture",
 ]
 HOST_SYMBOLS = ["rt_host_camera", "rt_host_build_scene", "rt_host_scene_camera", "rt_host_gen_rays",
                 "rt_gl_bind_buffer", "rt_gl_buffer_sub_data", "rt_gl_buffer_data", "rt_gl_buffer_bytes", "rt_gl_reset"]
@@ -163,5 +163,8 @@ def device_lib():
         lib.rt_last_build_ms.argtypes = [ctypes.c_void_p, P(ctypes.c_float)]
         lib.rt_lbvh_depth.restype = ctypes.c_int
         lib.rt_lbvh_depth.argtypes = [ctypes.c_void_p]
+        lib.rt_seed_texture.restype = ctypes.c_int
+        lib.rt_seed_texture.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                        ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
         _device = lib
     return _device

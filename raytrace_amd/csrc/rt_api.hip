@@ -18,6 +18,7 @@
 
 #include "../../include/raytrace_amd.h"
 #include "rt_kernels.cuh"
+#include "rt_seedtex.cuh"
 #include "rt_lbvh.cuh"
 
 namespace {
@@ -892,5 +893,23 @@ int rt_last_build_ms(rt_ctx* c, float* ms) {
 }
 
 int rt_lbvh_depth(rt_ctx* c) { return c ? c->depth : 0; }
+
+int rt_seed_texture(rt_ctx* c, int width, int height, float grid_size, float contrast, int layers, float lacunarity,
+                    uint32_t* seed_tex) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (width < 1 || height < 1 || (int64_t)width * height > (int64_t)1 << 30) return fail(RT_ERR_INVALID, "bad image size %d x %d", width, height);
+  if (layers < 0 || layers > 64) return fail(RT_ERR_INVALID, "bad layer count %d", layers);
+  if (!(grid_size != 0.0f)) return fail(RT_ERR_INVALID, "grid size must not be zero");
+  if (!seed_tex) return fail(RT_ERR_INVALID, "null output");
+  const size_t n = (size_t)width * height;
+  HIP_TRY(c->seed_tex.resize(n));
+  rt_seed_texture_kernel<<<dim3((width + 63) / 64, (height + 3) / 4), 256, 0, c->stream>>>(width, height, grid_size, contrast, layers,
+                                                                                           lacunarity, c->seed_tex.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(seed_tex, c->seed_tex.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RT_OK;
+}
 
 }  // extern "C"
