@@ -69,6 +69,24 @@ RT_API int rt_host_scene_camera(int scene, rt_camera* out);
  */
 RT_API int rt_host_gen_rays(uint32_t seed, uint64_t first, size_t n, float* o_xyz, float* d_xyz);
 
+/*
+ * The reference's presentation pass (raytrace.cpp:545-551, texFragment.fs:8-11):
+ * the RENDER_WIDTH x RENDER_HEIGHT RGB8 texture drawn over the whole
+ * SCREEN_WIDTH x SCREEN_HEIGHT window with GL_NEAREST (raytrace.cpp:576-577).
+ * Images here are rows from the top, as rt_readback returns them.  Window
+ * pixel (i, j) shows source texel (floor((2i+1) sw / (2 dw)),
+ * floor((2j+1) sh / (2 dh))) counted from the lower left, the texel under the
+ * pixel's centre, in exact integer arithmetic.  dst: dw*dh*3 bytes.
+ */
+RT_API int rt_host_blit_nearest(const uint8_t* src_rgb8, int sw, int sh, uint8_t* dst_rgb8, int dw, int dh);
+
+/* The window size the reference derives from a width and 16:9
+ * (raytrace.cpp:84-88,121-128): height = max(1, int(width / (16.0 / 9.0))). */
+RT_API int rt_host_height_for_width(int width);
+
+/* Binary PPM (P6) of an RGB8 image, rows from the top.  0 or RT_ERR_INVALID. */
+RT_API int rt_host_write_ppm(const char* path, const uint8_t* rgb8, int width, int height);
+
 #ifdef __cplusplus
 }
 #endif

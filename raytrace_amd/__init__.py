@@ -6,6 +6,7 @@ set-up run in the C++ host harness (raytrace_amd/host), rendering and hit tests
 in HIP kernels (raytrace_amd/csrc).
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -95,6 +96,28 @@ def gen_rays(seed, first, n):
     if rc:
         raise RtError(rc, "rt_host_gen_rays failed")
     return o, d
+
+
+def present(rgb8, window_width=1200):
+    """The reference's presentation pass: the rendered RGB8 image drawn over its 16:9 window with nearest
+    sampling (raytrace.cpp:84-88,545-551).  rgb8: uint8 [H,W,3], rows from the top."""
+    src = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    sh, sw, _ = src.shape
+    L = _lib.host_lib()
+    dh = L.rt_host_height_for_width(int(window_width))
+    dst = np.empty((dh, int(window_width), 3), dtype=np.uint8)
+    rc = L.rt_host_blit_nearest(src.ctypes.data, sw, sh, dst.ctypes.data, int(window_width), dh)
+    if rc:
+        raise RtError(rc, "rt_host_blit_nearest failed")
+    return dst
+
+
+def write_ppm(path, rgb8):
+    """Binary PPM of a uint8 [H,W,3] image, rows from the top."""
+    img = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    rc = _lib.host_lib().rt_host_write_ppm(os.fsencode(path), img.ctypes.data, img.shape[1], img.shape[0])
+    if rc:
+        raise RtError(rc, f"cannot write {path}")
 
 
 class Renderer:

@@ -70,6 +70,7 @@ DEVICE_SYMBOLS = [
     "rt_lbvh_depth", "rt_device_count", "rt_seed_texture",
 ]
 HOST_SYMBOLS = ["rt_host_camera", "rt_host_build_scene", "rt_host_scene_camera", "rt_host_gen_rays",
+                "rt_host_blit_nearest", "rt_host_height_for_width", "rt_host_write_ppm",
                 "rt_gl_bind_buffer", "rt_gl_buffer_sub_data", "rt_gl_buffer_data", "rt_gl_buffer_bytes", "rt_gl_reset"]
 
 _device = None
@@ -103,6 +104,12 @@ def host_lib():
         lib.rt_host_build_scene.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int)]
         lib.rt_host_scene_camera.restype = ctypes.c_int
         lib.rt_host_scene_camera.argtypes = [ctypes.c_int, ctypes.POINTER(RtCamera)]
+        lib.rt_host_blit_nearest.restype = ctypes.c_int
+        lib.rt_host_blit_nearest.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        lib.rt_host_height_for_width.restype = ctypes.c_int
+        lib.rt_host_height_for_width.argtypes = [ctypes.c_int]
+        lib.rt_host_write_ppm.restype = ctypes.c_int
+        lib.rt_host_write_ppm.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         lib.rt_host_gen_rays.restype = ctypes.c_int
         lib.rt_host_gen_rays.argtypes = [ctypes.c_uint32, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
         _host = lib

@@ -3,6 +3,7 @@
 // application would use it.  Plain C++, no GPU code.
 
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -314,6 +315,40 @@ int rt_host_gen_rays(uint32_t seed, uint64_t first, size_t n, float* o_xyz, floa
     for (auto& t : pool) t.join();
   }
   return RT_OK;
+}
+
+int rt_host_blit_nearest(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh) {
+  if (!src || !dst || sw < 1 || sh < 1 || dw < 1 || dh < 1) return RT_ERR_INVALID;
+  for (int jt = 0; jt < dh; jt++) {
+    const int j = dh - 1 - jt;  // window row from the bottom
+    const int r = (int)(((int64_t)(2 * j + 1) * sh) / (2 * (int64_t)dh));
+    const uint8_t* row = src + (size_t)(sh - 1 - r) * sw * 3;
+    uint8_t* out = dst + (size_t)jt * dw * 3;
+    for (int i = 0; i < dw; i++) {
+      const int c = (int)(((int64_t)(2 * i + 1) * sw) / (2 * (int64_t)dw));
+      out[3 * i] = row[3 * c];
+      out[3 * i + 1] = row[3 * c + 1];
+      out[3 * i + 2] = row[3 * c + 2];
+    }
+  }
+  return RT_OK;
+}
+
+int rt_host_height_for_width(int width) {
+  const double aspect_ratio = 16.0 / 9.0;  // raytrace.cpp:83, a double there too
+  const int h = (int)(width / aspect_ratio);
+  return h < 1 ? 1 : h;
+}
+
+int rt_host_write_ppm(const char* path, const uint8_t* rgb8, int width, int height) {
+  if (!path || !rgb8 || width < 1 || height < 1) return RT_ERR_INVALID;
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return RT_ERR_INVALID;
+  const size_t n = (size_t)width * height * 3;
+  bool ok = std::fprintf(f, "P6\n%d %d\n255\n", width, height) > 0;
+  ok = ok && std::fwrite(rgb8, 1, n, f) == n;
+  ok = (std::fclose(f) == 0) && ok;
+  return ok ? RT_OK : RT_ERR_INVALID;
 }
 
 }  // extern "C"

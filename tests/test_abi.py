@@ -26,7 +26,9 @@ def test_device_library_exports_every_declared_symbol():
 
 def test_host_library_exports_every_declared_symbol():
     names = declared("raytrace_amd_host.h")
-    assert set(names) == {"rt_host_camera", "rt_host_build_scene", "rt_host_scene_camera", "rt_host_gen_rays"}
+    assert set(names) == {n for n in _lib.HOST_SYMBOLS if n.startswith("rt_host_")}
+    assert {"rt_host_camera", "rt_host_build_scene", "rt_host_scene_camera", "rt_host_gen_rays",
+            "rt_host_blit_nearest", "rt_host_write_ppm"} <= set(names)
     lib = ctypes.CDLL(_lib.HOST_LIB)
     for n in names + ["rt_gl_bind_buffer", "rt_gl_buffer_sub_data", "rt_gl_buffer_data"]:
         assert hasattr(lib, n), n
