@@ -212,6 +212,31 @@ RT_API int rt_set_accumulator(rt_ctx* ctx, void* device_rgb, int width, int heig
 RT_API int rt_set_accumulated_samples(rt_ctx* ctx, int samples);
 
 /*
+ * Checkpoint and resume of a progressive render.  rt_accumulator_read copies
+ * out the raw per-pixel radiance sums (width*height*3 floats, host memory;
+ * sums may be NULL to query the size) and how many samples per pixel they
+ * hold; rt_accumulator_write puts such sums back (into the caller's
+ * accumulator if one is set, else the context's own) so that rendering goes on
+ * with sample_begin = samples.  With RT_RNG_COUNTER the finished image equals,
+ * bit for bit, the one an uninterrupted render gives: a pixel's sum is formed
+ * in sample order either way.  No counterpart in the reference, which renders
+ * once and keeps nothing.
+ */
+RT_API int rt_accumulator_read(rt_ctx* ctx, float* sums, int* width, int* height, int* samples);
+RT_API int rt_accumulator_write(rt_ctx* ctx, const float* sums, int width, int height, int samples);
+
+/*
+ * Replaces: shader_chunk_pass(vec2 c_min, vec2 c_max, Shader, Camera, fb_help
+ * fb, fb_help tex, hittable_list), raytrace.cpp:55,598-630 — the reference's
+ * (unfinished, never called) pass over one chunk of the frame.  Renders the
+ * sample range of p over pixels [c_min_x, c_max_x) x [c_min_y, c_max_y) and
+ * adds them to the accumulator; p's own tile rectangle is ignored.  Chunks and
+ * sample ranges may be issued in any order (RT_RNG_COUNTER) and compose to the
+ * full frame.
+ */
+RT_API int rt_render_chunk(rt_ctx* ctx, const rt_params* p, int c_min_x, int c_min_y, int c_max_x, int c_max_y);
+
+/*
  * Replaces: the end of the shader's main (colour / num_samples and the
  * 1/2.2 gamma, testFragment.fs:135-140) and the RGB8 colour attachment the
  * result lands in (raytrace.cpp:574).  Waits for the stream.  rgb_linear

@@ -436,7 +436,11 @@ V3 raycast(const Scene& sc, V3 o, V3 d, uint32_t bounce_limit, Rng& s, Counters&
 inline V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
 
 // One pixel of main(), fs:103-133: returns the SUM over the sample range.
-V3 pixel_sum(const Scene& sc, const rt_params& p, int x, int y, Counters& k) {
+// `colour` enters holding the pixel's sum over the samples rendered before
+// (zero for a fresh frame, fs:115) and leaves with this range added in sample
+// order, so that a frame rendered in several sample ranges, in order, is the
+// frame rendered in one.
+V3 pixel_sum(const Scene& sc, const rt_params& p, int x, int y, V3 colour, Counters& k) {
   Rng s;
   s.mode = p.rng_mode;
   const uint32_t pixel = (uint32_t)y * (uint32_t)p.width + (uint32_t)x;
@@ -450,7 +454,6 @@ V3 pixel_sum(const Scene& sc, const rt_params& p, int x, int y, Counters& k) {
   const V3 delta_u = ld3(p.delta_u), delta_v = ld3(p.delta_v);
   const V3 cam = ld3(p.camera_origin), vtl = ld3(p.viewport_top_left);
   const V3 ddu = ld3(p.defocus_disk_u), ddv = ld3(p.defocus_disk_v);
-  V3 colour = v3(0, 0, 0);
   for (int i = p.sample_begin; i < p.sample_end; i++) {  // fs:117
     if (p.rng_mode == RT_RNG_COUNTER) s.a = counter_key(p.seed, pixel, (uint32_t)i);
     float jx = rand_float(s) - 0.5f;  // fs:119
@@ -488,7 +491,7 @@ Scene make_scene(const void* spheres, int ns, const void* mats, int nm) {
 extern "C" {
 
 // Sum of radiance over samples [sample_begin, sample_end) for the pixels of the
-// tile, ADDED into accum (width*height*3 floats, row 0 on top).  `threads` rows
+// tile, added sample by sample onto accum (width*height*3 floats, row 0 on top).  `threads` rows
 // are rendered concurrently (row y goes to thread y % threads).
 int orc_render(const void* spheres_std140, int n_spheres, const void* materials_std140,
                int n_materials, const rt_params* p, float* accum, rt_counters* counters,
@@ -502,11 +505,11 @@ int orc_render(const void* spheres_std140, int n_spheres, const void* materials_
   auto work = [&](int tid) {
     for (int y = p->tile_y0 + tid; y < p->tile_y1; y += threads) {
       for (int x = p->tile_x0; x < p->tile_x1; x++) {
-        V3 c = pixel_sum(sc, *p, x, y, ks[(size_t)tid]);
         float* dst = accum + 3 * ((size_t)y * (size_t)p->width + (size_t)x);
-        dst[0] += c.x;
-        dst[1] += c.y;
-        dst[2] += c.z;
+        const V3 c = pixel_sum(sc, *p, x, y, v3(dst[0], dst[1], dst[2]), ks[(size_t)tid]);
+        dst[0] = c.x;
+        dst[1] = c.y;
+        dst[2] = c.z;
       }
     }
   };

@@ -168,7 +168,13 @@ class Renderer:
     def set_accumulated_samples(self, samples):
         self._check(self.lib.rt_set_accumulated_samples(self.ctx, int(samples)))
 
+    def _accumulator_size(self):
+        w, h = ctypes.c_int(), ctypes.c_int()
+        self._check(self.lib.rt_accumulator_read(self.ctx, None, ctypes.byref(w), ctypes.byref(h), None))
+        self.width, self.height = w.value, h.value
+
     def readback(self, linear=True, rgb8=True):
+        self._accumulator_size()
         n = self.width * self.height * 3
         lin = np.empty(n, dtype=np.float32) if linear else None
         q = np.empty(n, dtype=np.uint8) if rgb8 else None
@@ -214,6 +220,37 @@ class Renderer:
 
     def lbvh_depth(self):
         return int(self.lib.rt_lbvh_depth(self.ctx))
+
+    def render_chunk(self, params: RtParams, c_min, c_max):
+        """shader_chunk_pass of the reference (raytrace.cpp:598-630): pixels [c_min, c_max) of the frame."""
+        self._check(self.lib.rt_render_chunk(self.ctx, ctypes.byref(params), int(c_min[0]), int(c_min[1]), int(c_max[0]),
+                                             int(c_max[1])))
+
+    def render_progressive(self, params: RtParams, chunk=(256, 256), samples_per_pass=None):
+        """Generator: renders the frame chunk by chunk and pass by pass, yielding (samples_done, chunk_rect) after
+        each chunk so that a caller can display or checkpoint in between (counter RNG)."""
+        spp0, spp1 = params.sample_begin, params.sample_end
+        step = samples_per_pass or (spp1 - spp0)
+        for s in range(spp0, spp1, step):
+            p = params.copy()
+            p.sample_begin, p.sample_end = s, min(spp1, s + step)
+            for y0 in range(0, params.height, chunk[1]):
+                for x0 in range(0, params.width, chunk[0]):
+                    rect = (x0, y0, min(params.width, x0 + chunk[0]), min(params.height, y0 + chunk[1]))
+                    self.render_chunk(p, rect[:2], rect[2:])
+                    yield p.sample_end, rect
+
+    def checkpoint(self):
+        """(sums float32 [H,W,3], samples): the state a later restore() continues from."""
+        w, h, n = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self._check(self.lib.rt_accumulator_read(self.ctx, None, ctypes.byref(w), ctypes.byref(h), ctypes.byref(n)))
+        sums = np.empty((h.value, w.value, 3), dtype=np.float32)
+        self._check(self.lib.rt_accumulator_read(self.ctx, sums.ctypes.data, None, None, None))
+        return sums, n.value
+
+    def restore(self, sums, samples):
+        sums = np.ascontiguousarray(sums, dtype=np.float32)
+        self._check(self.lib.rt_accumulator_write(self.ctx, sums.ctypes.data, sums.shape[1], sums.shape[0], int(samples)))
 
     def seed_texture(self, width, height, grid=400.0, contrast=1.5, layers=12, lacunarity=1.5):
         """The reference's seed image (perlin.fs pass, raytrace.cpp:309-328) as rt_params.seed_tex words."""

@@ -67,7 +67,8 @@ DEVICE_SYMBOLS = [
     "rt_gl_buffer_bytes", "rt_gl_reset", "rt_gl_dropped_writes", "rt_scene_upload", "rt_render", "rt_render_counted",
     "rt_clear", "rt_set_accumulator", "rt_set_accumulated_samples", "rt_readback", "rt_trace_batch",
     "rt_trace_batch_device", "rt_synchronize", "rt_get_counters", "rt_last_kernel_ms", "rt_last_build_ms",
-    "rt_lbvh_depth", "rt_device_count", "rt_seed_texture",
+    "rt_lbvh_depth", "rt_device_count", "rt_seed_texture", "rt_accumulator_read", "rt_accumulator_write",
+    "rt_render_chunk",
 ]
 HOST_SYMBOLS = ["rt_host_camera", "rt_host_build_scene", "rt_host_scene_camera", "rt_host_gen_rays",
                 "rt_host_blit_nearest", "rt_host_height_for_width", "rt_host_write_ppm",
@@ -170,6 +171,14 @@ def device_lib():
         lib.rt_last_build_ms.argtypes = [ctypes.c_void_p, P(ctypes.c_float)]
         lib.rt_lbvh_depth.restype = ctypes.c_int
         lib.rt_lbvh_depth.argtypes = [ctypes.c_void_p]
+        lib.rt_accumulator_read.restype = ctypes.c_int
+        lib.rt_accumulator_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int),
+                                            ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        lib.rt_accumulator_write.restype = ctypes.c_int
+        lib.rt_accumulator_write.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        lib.rt_render_chunk.restype = ctypes.c_int
+        lib.rt_render_chunk.argtypes = [ctypes.c_void_p, ctypes.POINTER(RtParams), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int]
         lib.rt_seed_texture.restype = ctypes.c_int
         lib.rt_seed_texture.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                         ctypes.c_int, ctypes.c_float, ctypes.c_void_p]

@@ -756,6 +756,53 @@ int rt_set_accumulated_samples(rt_ctx* c, int samples) {
   return RT_OK;
 }
 
+int rt_accumulator_read(rt_ctx* c, float* sums, int* width, int* height, int* samples) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!c->accum() || c->acc_w < 1) return fail(RT_ERR_STATE, "nothing rendered yet");
+  if (width) *width = c->acc_w;
+  if (height) *height = c->acc_h;
+  if (samples) *samples = c->samples_override > 0 ? c->samples_override : c->samples_hi - c->samples_lo;
+  if (sums) {
+    const size_t nv = 3 * (size_t)c->acc_w * (size_t)c->acc_h;
+    HIP_TRY(hipMemcpyAsync(sums, c->accum(), nv * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RT_OK;
+}
+
+int rt_accumulator_write(rt_ctx* c, const float* sums, int width, int height, int samples) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!sums || width < 1 || height < 1 || (int64_t)width * height > (int64_t)1 << 30) return fail(RT_ERR_INVALID, "bad accumulator image");
+  if (samples < 0) return fail(RT_ERR_INVALID, "negative sample count");
+  const size_t nv = 3 * (size_t)width * (size_t)height;
+  if (c->accum_ext) {
+    if (width != c->acc_w || height != c->acc_h)
+      return fail(RT_ERR_STATE, "image %d x %d does not match the caller's accumulator %d x %d", width, height, c->acc_w, c->acc_h);
+  } else {
+    HIP_TRY(c->accum_own.resize(nv));
+    c->acc_w = width;
+    c->acc_h = height;
+  }
+  HIP_TRY(hipMemcpyAsync(c->accum(), sums, nv * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->samples_lo = 0;
+  c->samples_hi = samples;
+  c->samples_override = -1;
+  return RT_OK;
+}
+
+int rt_render_chunk(rt_ctx* c, const rt_params* p, int c_min_x, int c_min_y, int c_max_x, int c_max_y) {
+  if (!p) return fail(RT_ERR_INVALID, "null params");
+  rt_params q = *p;
+  q.tile_x0 = c_min_x;
+  q.tile_y0 = c_min_y;
+  q.tile_x1 = c_max_x;
+  q.tile_y1 = c_max_y;
+  return render_impl(c, &q, false);
+}
+
 int rt_readback(rt_ctx* c, float* rgb_linear, uint8_t* rgb8) {
   int rc = check_ctx(c);
   if (rc) return rc;

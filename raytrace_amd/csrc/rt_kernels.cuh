@@ -313,9 +313,9 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       A.carry_idx[rect_pixel] = rect_pixel;
     } else {
       float* dst = A.accum + 3 * (size_t)pixel;
-      dst[0] += colour.x;
-      dst[1] += colour.y;
-      dst[2] += colour.z;
+      dst[0] = colour.x;
+      dst[1] = colour.y;
+      dst[2] = colour.z;
     }
     have = false;
   };
@@ -425,7 +425,10 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
               colour = mk3(src[0], src[1], src[2]);
               rng = A.carry_rng[rect_pixel];
             } else {
-              colour = mk3(0.0f, 0.0f, 0.0f);
+              // the sum goes on from what earlier sample ranges left in the image (zero on a
+              // fresh frame, fs:115): ranges rendered in order add up exactly as one render
+              const float* src = A.accum + 3 * (size_t)pixel;
+              colour = mk3(src[0], src[1], src[2]);
               if (RNG == RT_RNG_XORSHIFT_REF) {
                 const uint32_t seed = A.seed_tex ? A.seed_tex[pixel] : 0u;  // fs:105-106
                 rng = seed ^ cantor_pair((uint32_t)x, (uint32_t)y);         // fs:107

@@ -167,14 +167,22 @@ def test_tiles_and_sample_ranges_compose(renderer):
             renderer.render(q)
     tiled, _ = renderer.readback(rgb8=False)
     assert_same_f32(tiled, whole, "tiled image")
-    # sample ranges: same pixels, partial sums added in a different order
+    # sample ranges in order: every pixel's sum goes on from the accumulator -> bit-identical
     renderer.clear()
     for (s0, s1) in ((0, 2), (2, S)):
         q = p.copy()
         q.sample_begin, q.sample_end = s0, s1
         renderer.render(q)
     split, _ = renderer.readback(rgb8=False)
-    np.testing.assert_allclose(split, whole, rtol=1e-5, atol=1e-6)
+    assert_same_f32(split, whole, "image from two sample ranges")
+    # out of order: the same samples, summed in another order
+    renderer.clear()
+    for (s0, s1) in ((2, S), (0, 2)):
+        q = p.copy()
+        q.sample_begin, q.sample_end = s0, s1
+        renderer.render(q)
+    swapped, _ = renderer.readback(rgb8=False)
+    np.testing.assert_allclose(swapped, whole, rtol=1e-5, atol=1e-6)
 
 
 def test_edge_cases(renderer):
