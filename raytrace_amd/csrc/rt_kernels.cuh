@@ -24,7 +24,7 @@ enum {
 #define RT_TRACE_WAVES 5
 #endif
 #ifndef RT_LINEAR_WAVES
-#define RT_LINEAR_WAVES 5
+#define RT_LINEAR_WAVES 4
 #endif
 
 template <int SEARCH>

@@ -68,12 +68,17 @@ struct scene_view {
 // in every lane, so a sphere record is one broadcast LDS read (or one scalar
 // load when the scene is too large for LDS) per wave.
 //
-// The expensive part of hit_sphere is the correctly rounded sqrt and divide of
-// the roots; they only matter when the sphere can replace the current closest
-// hit.  The accepted root is never below the near root, so a sphere whose near
-// root — estimated with the hardware's 1-ulp sqrt / rcp and a slack of 8u
-// times the terms that were subtracted — already lies beyond the closest hit
-// cannot satisfy "new_t < t" (fs:180) and is skipped without computing it.
+// Only a sphere whose discriminant is not negative can change the running hit
+// (hit_sphere returns -1 otherwise, fs:161, and -1 is never accepted over a hit
+// nor different from "no hit yet").  The scan therefore runs in blocks of 32
+// spheres of straight-line code — discriminants only, each lane shifting the
+// outcome into a bit mask — and after each block every lane evaluates the roots
+// (correctly rounded sqrt and divides) of its own candidates, lowest index
+// first, which applies the accept rule of fs:180 to the same spheres in the
+// same order as the shader's loop.  There a sphere whose near root — estimated
+// with the hardware's 1-ulp sqrt / rcp and a slack of 8u times the terms that
+// were subtracted — already lies beyond the closest hit cannot satisfy
+// "new_t < t" and is skipped.
 // Returns t (-1 or a stuck NaN mean "no hit": the caller tests t > 0.001) and
 // the index that produced it.
 // ---------------------------------------------------------------------------
@@ -85,51 +90,91 @@ RT_DEV void hit_linear(const float4* sph, int n, f3 o, f3 d, float& t_out, int& 
   float best_t = -1.0f;
   int best_i = -1;
   RT_COUNT(k, sphere_tests, (uint32_t)n);
-  auto test = [&](const float4 s, int i) {
+  uint32_t mask = 0;
+  auto test = [&](const float4 s) {
     float h, disc;
     sphere_disc(s.x, s.y, s.z, s.w, o, d, a, h, disc);
-    if (disc >= 0.0f) {
-      bool need_exact = true;
-      if (can_estimate && !(best_t < 0.0f)) {
-        const float sq = __builtin_amdgcn_sqrtf(disc);
-        const float near_t = (h - sq) * rcp_a;
-        const float slack = 1.0e-6f * ((fabsf(h) + sq) * rcp_a);
-        need_exact = near_t - slack < best_t;
-      }
-      if (need_exact) {
-        float t = sphere_roots<COUNTED>(h, disc, a, k);
-        if (best_t < 0.0f || (t < best_t && t > 0.001f)) {  // fs:180
-          best_t = t;
-          best_i = i;
-        }
+    mask = (mask << 1) | (disc >= 0.0f ? 1u : 0u);
+  };
+  auto evaluate = [&](int i) {
+    const float4 s = sph[i];
+    float h, disc;
+    sphere_disc(s.x, s.y, s.z, s.w, o, d, a, h, disc);  // the same operations on the same inputs: the same bits
+    bool need_exact = true;
+    if (can_estimate && !(best_t < 0.0f)) {
+      const float sq = __builtin_amdgcn_sqrtf(disc);
+      const float near_t = (h - sq) * rcp_a;
+      const float slack = 1.0e-6f * ((fabsf(h) + sq) * rcp_a);
+      need_exact = near_t - slack < best_t;
+    }
+    if (need_exact) {
+      float t = sphere_roots<COUNTED>(h, disc, a, k);
+      if (best_t < 0.0f || (t < best_t && t > 0.001f)) {  // fs:180
+        best_t = t;
+        best_i = i;
       }
     }
   };
-  // Groups of four records, the next group's loads issued before the current
-  // group is tested, so that the record latency hides behind the arithmetic.
+  // Records are read four at a time, the next four before the current four are
+  // tested, so that their latency hides behind the arithmetic; two register
+  // sets take turns, so that nothing is copied from "next" to "current".
   const int last = n - 1;
-  float4 n0, n1, n2, n3;
+  float4 n0, n1, n2, n3, m0, m1, m2, m3;
   if (n > 0) {
     n0 = sph[0];
     n1 = sph[min(1, last)];
     n2 = sph[min(2, last)];
     n3 = sph[min(3, last)];
   }
-  int i = 0;
-  for (; i + 4 <= n; i += 4) {
-    const float4 c0 = n0, c1 = n1, c2 = n2, c3 = n3;
-    n0 = sph[min(i + 4, last)];
-    n1 = sph[min(i + 5, last)];
-    n2 = sph[min(i + 6, last)];
-    n3 = sph[min(i + 7, last)];
-    test(c0, i);
-    test(c1, i + 1);
-    test(c2, i + 2);
-    test(c3, i + 3);
+  for (int base = 0; base < n; base += 32) {
+    const int cnt = min(32, n - base);
+    mask = 0;
+    int j = 0;
+    for (; j + 8 <= cnt; j += 8) {
+      const int nx = base + j + 4;
+      m0 = sph[min(nx, last)];
+      m1 = sph[min(nx + 1, last)];
+      m2 = sph[min(nx + 2, last)];
+      m3 = sph[min(nx + 3, last)];
+      test(n0);
+      test(n1);
+      test(n2);
+      test(n3);
+      n0 = sph[min(nx + 4, last)];
+      n1 = sph[min(nx + 5, last)];
+      n2 = sph[min(nx + 6, last)];
+      n3 = sph[min(nx + 7, last)];
+      test(m0);
+      test(m1);
+      test(m2);
+      test(m3);
+    }
+    if (j + 4 <= cnt) {
+      const int nx = base + j + 4;
+      m0 = sph[min(nx, last)];
+      m1 = sph[min(nx + 1, last)];
+      m2 = sph[min(nx + 2, last)];
+      m3 = sph[min(nx + 3, last)];
+      test(n0);
+      test(n1);
+      test(n2);
+      test(n3);
+      n0 = m0;
+      n1 = m1;
+      n2 = m2;
+      n3 = m3;
+      j += 4;
+    }
+    if (j < cnt) test(n0);  // the last block's tail: fewer than four left
+    if (j + 1 < cnt) test(n1);
+    if (j + 2 < cnt) test(n2);
+    mask <<= 32 - cnt;  // sphere base + b sits at bit 31 - b
+    while (mask != 0u) {
+      const int b = __clz(mask);
+      mask &= ~(0x80000000u >> b);
+      evaluate(base + b);
+    }
   }
-  if (i < n) test(n0, i);
-  if (i + 1 < n) test(n1, i + 1);
-  if (i + 2 < n) test(n2, i + 2);
   t_out = best_t;
   i_out = best_i;
 }
