@@ -36,7 +36,8 @@ struct search_traits {
   static constexpr int waves = lds ? 16 : 4;       // waves per workgroup
   static constexpr int threads = waves * 64;
   static constexpr int stack = lds ? 16 : 8;       // entries per lane kept in LDS
-  static constexpr int stack_words = !tree ? 0 : (lds ? stack * 64 : stack * 128);  // per wave
+  // per wave; the one-word stacks of LDS trees carry one more row, the sink of stores that must not land
+  static constexpr int stack_words = !tree ? 0 : (lds ? (stack + 1) * 64 : stack * 128);
   // Waves per SIMD the register allocation of the render kernel aims for.
   static constexpr int render_waves_per_simd = tree ? 4 : RT_LINEAR_WAVES;
   // The closest-hit kernel on an HBM-resident tree waits on node fetches: more waves hide more of them.

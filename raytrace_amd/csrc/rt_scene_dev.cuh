@@ -419,9 +419,10 @@ struct tree_search {
     for (int ch = 0; ch < 4; ch++) {
       ok[ch] = tn[ch] <= tf[ch] && refs[ch] != RT_REF_EMPTY;
       RT_COUNT(k, node_tests, refs[ch] != RT_REF_EMPTY ? 1u : 0u);
-      if (ok[ch] && refs[ch] < 0) {
-        if (LEAF_INLINE) leaf_mask |= 1u << ch;
-        else lq.push(~refs[ch]);
+      if (LEAF_INLINE) {
+        leaf_mask |= (ok[ch] ? ((uint32_t)refs[ch] >> 31) : 0u) << ch;  // arithmetic, not a branch per child
+      } else if (ok[ch] && refs[ch] < 0) {
+        lq.push(~refs[ch]);
       }
     }
     // LDS-resident scenes test the leaves here and now (an exact hit shortens the
@@ -451,15 +452,20 @@ struct tree_search {
   } while (0)
       RT_CE(0, 1); RT_CE(2, 3); RT_CE(0, 2); RT_CE(1, 3); RT_CE(1, 2);
 #undef RT_CE
-      // farthest first, so the nearest is popped first
+      // The nearest child is next; the others go on the stack, farthest first, so
+      // that the nearest of them is popped first.  Three unconditional stores:
+      // key[e] of cnt valid keys belongs at sp + cnt-1-e; the keys that are not
+      // valid, and those that do not fit, go to row STACK, which nobody reads.
+      const int cnt = (key[0] != 0xFFFFFFFFu ? 1 : 0) + (key[1] != 0xFFFFFFFFu ? 1 : 0) + (key[2] != 0xFFFFFFFFu ? 1 : 0) +
+                      (key[3] != 0xFFFFFFFFu ? 1 : 0);
 #pragma unroll
-      for (int e = 3; e >= 1; e--) {
-        if (key[e] != 0xFFFFFFFFu) {
-          if (sp < STACK) stk.col[sp * 64] = key[e];
-          else c.redo = true;
-          sp += sp < STACK ? 1 : 0;
-        }
+      for (int e = 1; e <= 3; e++) {
+        const int row = e < cnt ? min(sp + cnt - 1 - e, STACK) : STACK;
+        stk.col[row * 64] = key[e];
       }
+      const int grown = sp + max(cnt - 1, 0);
+      c.redo = c.redo || grown > STACK;
+      sp = min(grown, STACK);
       if (key[0] != 0xFFFFFFFFu) {
         cur = trav_stack<true>::key_ref(key[0]);
         return;
