@@ -15,6 +15,7 @@
 
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "../../include/raytrace_amd.h"
 #include "rt_kernels.cuh"
@@ -65,6 +66,8 @@ struct dev_buf {
   }
 };
 
+// Memory for the per-sample radiance of pixels whose main pass is cut into several jobs.
+constexpr size_t kSplitBudgetBytes = (size_t)1 << 30;
 // Largest dynamic LDS a launch may ask for (the CU has 160 KiB).
 constexpr size_t kMaxLdsBytes = 160 * 1024;
 // The linear scan stages its sphere records in LDS up to this many bytes.
@@ -118,6 +121,12 @@ struct rt_ctx {
   dev_buf<float> carry_colour;
   dev_buf<uint32_t> carry_rng, carry_key, carry_idx, order_key, order_idx;
   dev_buf<unsigned char> sort_temp;
+  // main-pass jobs: parts per sorted pixel, their prefix sum, the job table, totals, per-sample store of split pixels
+  dev_buf<uint32_t> plan_parts, plan_first, plan_counts;
+  dev_buf<unsigned long long> plan_total;
+  dev_buf<uint4> plan_jobs;
+  dev_buf<float> split_samples;
+  dev_buf<unsigned char> scan_temp;
   int n_cu = 0;
   dev_buf<unsigned long long> counters;
   dev_buf<float> out_linear;
@@ -498,7 +507,10 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
     }
   };
   a.pass = 0;
-  a.order = nullptr;
+  a.jobs = nullptr;
+  a.n_jobs = nullptr;
+  a.split_samples = nullptr;
+  a.main_samples = 0;
   a.carry_colour = nullptr;
   a.carry_rng = a.carry_key = a.carry_idx = nullptr;
   // A pixel is the unit of work (its sum must be formed in sample order), so
@@ -536,12 +548,51 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       e = rocprim::radix_sort_pairs(c->sort_temp.p, temp_bytes, c->carry_key.p, c->order_key.p, c->carry_idx.p,
                                     c->order_idx.p, n_rect, 0, 12, c->stream);
     if (e == hipSuccess) {
+      // Plan the main pass: one job per pixel, except that the most expensive pixels are cut into
+      // several sample ranges (counter RNG only: the reference's generator runs through a pixel's
+      // samples and cannot start in the middle).
+      const int main_begin = p->sample_begin + kProbeSamples, main_samples = p->sample_end - main_begin;
+      const uint32_t n = (uint32_t)n_rect;
+      const uint32_t lanes = (uint32_t)c->n_cu * 2048u;  // more than any launch keeps resident: jobs err on the small side
+      size_t want = kSplitBudgetBytes / ((size_t)main_samples * 3 * sizeof(float));
+      const uint32_t max_split = (uint32_t)(want > 65536 ? 65536 : want);
+      const int splittable = p->rng_mode == RT_RNG_COUNTER && max_split > 0 ? 1 : 0;
+      HIP_TRY(c->plan_parts.resize(n));
+      HIP_TRY(c->plan_first.resize(n));
+      HIP_TRY(c->plan_counts.resize(1));
+      HIP_TRY(c->plan_total.resize(1));
+      HIP_TRY(c->plan_jobs.resize((size_t)n + 8ull * lanes + 64));
+      if (splittable) HIP_TRY(c->split_samples.resize((size_t)max_split * (size_t)main_samples * 3));
+      size_t scan_bytes = 0;
+      HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, c->plan_parts.p, c->plan_first.p, 0u, n, rocprim::plus<uint32_t>(), c->stream));
+      HIP_TRY(c->scan_temp.resize(scan_bytes > 0 ? scan_bytes : 1));
+      HIP_TRY(hipMemsetAsync(c->plan_total.p, 0, sizeof(unsigned long long), c->stream));
+      const unsigned grid = (n + 255) / 256;
+      rt_plan_cost_kernel<<<grid < 1024 ? grid : 1024, 256, 0, c->stream>>>(c->order_key.p, n, c->plan_total.p);
+      rt_plan_count_kernel<<<grid, 256, 0, c->stream>>>(c->order_key.p, n, c->plan_total.p, lanes, max_split, main_samples,
+                                                       splittable, c->plan_parts.p);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(rocprim::exclusive_scan(c->scan_temp.p, scan_bytes, c->plan_parts.p, c->plan_first.p, 0u, n, rocprim::plus<uint32_t>(),
+                                      c->stream));
+      rt_plan_jobs_kernel<<<grid, 256, 0, c->stream>>>(c->order_idx.p, c->plan_parts.p, c->plan_first.p, n, main_begin,
+                                                      p->sample_end, c->plan_jobs.p, c->plan_counts.p);
+      HIP_TRY(hipGetLastError());
       render_args mainp = probe;
       mainp.pass = 2;
-      mainp.p.sample_begin = p->sample_begin + kProbeSamples;
+      mainp.p.sample_begin = main_begin;
       mainp.p.sample_end = p->sample_end;
-      mainp.order = c->order_idx.p;
+      mainp.jobs = c->plan_jobs.p;
+      mainp.n_jobs = c->plan_counts.p;
+      mainp.split_samples = c->split_samples.p;
+      mainp.main_samples = main_samples;
       e = launch(mainp, p);
+      if (e == hipSuccess && splittable) {
+        const uint32_t cand = n < max_split ? n : max_split;
+        rt_sum_split_kernel<<<(cand + 255) / 256, 256, 0, c->stream>>>(c->order_idx.p, c->plan_parts.p, cand, c->carry_colour.p,
+                                                                      c->split_samples.p, main_samples, p->tile_x0, p->tile_y0,
+                                                                      tw, p->width, c->accum());
+        e = hipGetLastError();
+      }
     }
   }
   if (e != hipSuccess) return fail(RT_ERR_DEVICE, "render launch: %s", hipGetErrorString(e));
@@ -600,6 +651,8 @@ void rt_destroy(rt_ctx* c) {
   c->nodes.release(); c->leaf_sph.release(); c->leaf_r.release(); c->leaf_idx.release();
   c->accum_own.release(); c->seed_tex.release(); c->queue.release(); c->counters.release(); c->ovf.release();
   c->carry_colour.release(); c->carry_rng.release(); c->carry_key.release(); c->carry_idx.release();
+  c->plan_parts.release(); c->plan_first.release(); c->plan_counts.release(); c->plan_total.release();
+  c->plan_jobs.release(); c->split_samples.release(); c->scan_temp.release();
   c->order_key.release(); c->order_idx.release(); c->sort_temp.release(); c->out_linear.release(); c->out_rgb8.release();
   if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
   if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);

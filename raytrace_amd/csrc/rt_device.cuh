@@ -118,6 +118,9 @@ RT_DEV f3 random_unit_vector(uint32_t& a, lane_counters& k) {
     f3 p = mk3(x, y, z);
     float lensq = dot3(p, p);
     RT_COUNT(k, unit_tries, 1);
+#ifdef RT_ABL_ONE_TRY  // timing experiments only: wrong results
+    return div3(p, sqrtf(lensq));
+#endif
     if (0.0f < lensq && lensq <= 1.0f) return div3(p, sqrtf(lensq));
     i += 1u;
   }
@@ -133,6 +136,9 @@ RT_DEV f3 random_unit_disk(uint32_t& a, lane_counters& k) {
     float y = rng_float<RNG>(a);
     float lensq = (x * x + y * y) + 0.0f * 0.0f;
     RT_COUNT(k, disk_tries, 1);
+#ifdef RT_ABL_ONE_TRY
+    return mk3(x, y, 0.0f);
+#endif
     if (lensq <= 1.0f) return mk3(x, y, 0.0f);
     i += 1u;
   }
@@ -252,6 +258,14 @@ struct hit_rec {
 template <int RNG, bool COUNTED>
 RT_DEV bool shade_hit(const hit_rec& h, int type, float param1, f3 m_albedo, f3& dir, f3& albedo, uint32_t& rng,
                       lane_counters& k) {
+#ifdef RT_ABL_LAMBERT_ONLY  // timing experiments only: wrong results
+  type = RT_MAT_LAMBERTIAN;
+#endif
+#ifdef RT_ABL_NO_SHADE
+  dir = h.normal + mk3(0.3f, 0.2f, 0.1f);
+  albedo = albedo * m_albedo;
+  return true;
+#endif
   const bool diffuse = type == RT_MAT_LAMBERTIAN || type == RT_MAT_PERLIN_LAMBERTIAN;
   const bool metal = type == RT_MAT_METALLIC;
   f3 ruv = mk3(0.0f, 0.0f, 0.0f);

@@ -56,7 +56,7 @@ inline size_t search_scene_lds_bytes(const scene_counts& n) {
   using T = search_traits<SEARCH>;
   if (T::scan_lds) return (size_t)n.n_spheres * 16;
   if (!T::lds) return 0;
-  return (size_t)n.n_nodes * sizeof(bvh4_node) + (size_t)n.n_leaf * 16 + pad16((size_t)n.n_leaf * 4) +
+  return (size_t)n.n_nodes * RT_LDS_NODE_STRIDE + (size_t)n.n_leaf * 16 + pad16((size_t)n.n_leaf * 4) +
          (size_t)n.n_spheres * 16 + 2 * pad16((size_t)n.n_spheres * 4) + (size_t)n.n_materials * 16 +
          pad16((size_t)n.n_materials * 4);
 }
@@ -81,15 +81,24 @@ struct render_args {
   //   pass 0  everything in one launch, queue in tile order
   //   pass 1  probe: the first few samples of every pixel in tile order; leaves the pixel's
   //           running sum, RNG state and segment count in the carry arrays, not in accum
-  //   pass 2  main: the remaining samples, pixels taken from `order` (most expensive first),
-  //           each continuing from its carried sum and RNG state
+  //   pass 2  main: the remaining samples, taken job by job (most expensive pixels first),
+  //           each pixel continuing from its carried sum and RNG state
   int pass;
-  const uint32_t* order;       // pass 2: rect-pixel indices, heaviest first
   float* carry_colour;         // 3 floats per rect pixel
   uint32_t* carry_rng;
   uint32_t* carry_key;         // pass 1 writes the sort key (small = expensive) ...
   uint32_t* carry_idx;         // ... and the rect-pixel index it belongs to
+  // Pass 2 takes jobs, not pixels: a pixel so expensive that it alone would outlast the rest of
+  // the launch is cut into several sample ranges.  The lanes working on such a pixel store every
+  // sample's radiance, and rt_sum_split_kernel adds them up in sample order afterwards, which
+  // keeps the pixel's sum bit-identical to a sequential evaluation.
+  const uint4* jobs;           // (rect pixel, first sample, end sample, split row or RT_JOB_WHOLE)
+  const uint32_t* n_jobs;      // how many there are (computed on the device)
+  float* split_samples;        // split row r, sample s of the main pass: 3 floats at (r * main_samples + s) * 3
+  int main_samples;            // samples per pixel of the main pass
 };
+
+#define RT_JOB_WHOLE 0xFFFFFFFFu
 
 template <bool COUNTED>
 RT_DEV void flush_counters(unsigned long long* g, const lane_counters& k) {
@@ -143,9 +152,9 @@ RT_DEV void search_setup(const scene_dev& sc, scene_view& sv, uint32_t*& stack_c
     {
       float4* d = reinterpret_cast<float4*>(base);
       const float4* src = reinterpret_cast<const float4*>(sc.nodes);
-      for (int i = threadIdx.x; i < sc.n_nodes * 8; i += T::threads) d[i] = src[i];
+      for (int i = threadIdx.x; i < sc.n_nodes * 8; i += T::threads) d[(i >> 3) * (RT_LDS_NODE_STRIDE / 16) + (i & 7)] = src[i];
       sv.nodes = reinterpret_cast<const bvh4_node*>(d);
-      base += (size_t)sc.n_nodes * sizeof(bvh4_node);
+      base += (size_t)sc.n_nodes * RT_LDS_NODE_STRIDE;
     }
 #define RT_LDS_COPY(field, type, count)                                       \
   {                                                                           \
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
 
   const int tw = P.tile_x1 - P.tile_x0, th = P.tile_y1 - P.tile_y0;
   const int tiles_x = (tw + 7) >> 3, tiles_y = (th + 7) >> 3;
-  const uint32_t total_items = A.pass == 2 ? (uint32_t)tw * (uint32_t)th : (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
+  const uint32_t total_items = A.pass == 2 ? *A.n_jobs : (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
 
   lane_counters k = {};
   const f3 delta_u = mk3(P.delta_u[0], P.delta_u[1], P.delta_u[2]);
@@ -295,8 +304,8 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
   bool pending = false;     // a finished search waits to be shaded
   bool in_trav = false;     // the search needs more steps
   bool exhausted = P.sample_end <= P.sample_begin;
-  int x = 0, y = 0, s = 0;
-  uint32_t pixel = 0, rect_pixel = 0, rng = 0, count = 0, pixel_segments = 0;
+  int x = 0, y = 0, s = 0, s_end = P.sample_end;
+  uint32_t pixel = 0, rect_pixel = 0, rng = 0, count = 0, pixel_segments = 0, split_row = RT_JOB_WHOLE;
   f3 colour = mk3(0.0f, 0.0f, 0.0f);
   f3 alb = colour;
   uint32_t pool_next = 0, pool_end = 0;  // the wave's share of the pixel queue
@@ -312,13 +321,25 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       A.carry_rng[rect_pixel] = rng;
       A.carry_key[rect_pixel] = 4095u - min(pixel_segments, 4095u);
       A.carry_idx[rect_pixel] = rect_pixel;
-    } else {
+    } else if (split_row == RT_JOB_WHOLE) {
       float* dst = A.accum + 3 * (size_t)pixel;
       dst[0] = colour.x;
       dst[1] = colour.y;
       dst[2] = colour.z;
     }
     have = false;
+  };
+  // The finished path's radiance joins the pixel's running sum, or, for a pixel cut into
+  // several jobs, goes to its own slot to be summed in order later.
+  auto add_sample = [&]() {
+    if (split_row == RT_JOB_WHOLE) {
+      colour = colour + alb;
+    } else {
+      float* dst = A.split_samples + ((size_t)split_row * (size_t)A.main_samples + (size_t)(s - P.sample_begin)) * 3;
+      dst[0] = alb.x;
+      dst[1] = alb.y;
+      dst[2] = alb.z;
+    }
   };
 
   RT_CLK_DECL
@@ -391,10 +412,10 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
         srch.ts.d = d;
         start_segment = true;
       } else {  // fs:132: colour += raycast(...)
-        colour = colour + alb;
+        add_sample();
         alive = false;
         s++;
-        if (s >= P.sample_end) close_pixel();
+        if (s >= s_end) close_pixel();
       }
     }
     RT_CLK_STOP(3);
@@ -405,8 +426,10 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
         if (item >= total_items) {
           exhausted = true;
         } else {
+          uint4 job = make_uint4(0u, (uint32_t)P.sample_begin, (uint32_t)P.sample_end, RT_JOB_WHOLE);
           if (A.pass == 2) {
-            rect_pixel = A.order[item];
+            job = A.jobs[item];
+            rect_pixel = job.x;
             x = P.tile_x0 + (int)(rect_pixel % (uint32_t)tw);
             y = P.tile_y0 + (int)(rect_pixel / (uint32_t)tw);
           } else {
@@ -418,7 +441,9 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
           if (x < P.tile_x1 && y < P.tile_y1) {
             have = true;
             pixel = (uint32_t)y * (uint32_t)P.width + (uint32_t)x;
-            s = P.sample_begin;
+            s = (int)job.y;
+            s_end = (int)job.z;
+            split_row = job.w;
             alive = false;
             pixel_segments = 0;
             if (A.pass == 2) {  // continue the sum and the RNG stream the probe pass left
@@ -456,10 +481,10 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
         if (P.bounce_limit == 0u) {  // fs:203-205 on the first bounce()
           alb = mk3(0.0f, 0.0f, 0.0f);
           RT_COUNT(k, limit_hits, 1);
-          colour = colour + alb;
+          add_sample();
           alive = false;
           s++;
-          if (s >= P.sample_end) close_pixel();
+          if (s >= s_end) close_pixel();
         } else {
           srch.ts.o = ro;
           srch.ts.d = frag - ro;
@@ -478,12 +503,81 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
   }
 #ifdef RT_SECTION_CLOCKS
   if (COUNTED && A.counters != nullptr && (threadIdx.x & 63) == 0) {
-    clk_[6] = __builtin_amdgcn_s_memtime() - clk_0_;
+    const unsigned long long end_ = __builtin_amdgcn_s_memtime();
+    clk_[6] = end_ - clk_0_;
     for (int i = 0; i < 7; i++) atomicAdd(A.counters + 5 + i, clk_[i]);
+    atomicMax(A.counters + 12, clk_[6]);  // disk_tries: the longest-running wave
+    atomicAdd(A.counters + 13, 1ull);     // limit_hits: waves
   }
-  k.hits = k.sky = k.lambertian = k.metallic = k.dialectric = k.perlin = k.unit_tries = 0;
+  k.hits = k.sky = k.lambertian = k.metallic = k.dialectric = k.perlin = k.unit_tries = k.disk_tries = k.limit_hits = 0;
 #endif
   flush_counters<COUNTED>(A.counters, k);
+}
+
+// ---- job planning for the main pass of two-pass rendering --------------------
+// keys[i] (sorted ascending) = 4095 - segments the probe pass spent on pixel order[i].
+
+__global__ __launch_bounds__(256) void rt_plan_cost_kernel(const uint32_t* keys, uint32_t n, unsigned long long* total) {
+  unsigned long long sum = 0;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) sum += 4095u - keys[i];
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if ((threadIdx.x & 63) == 0 && sum != 0) atomicAdd(total, sum);
+}
+
+// Jobs of pixel i: its share of the measured cost in units of 1/(8 * lanes) of the total, so that no
+// job is longer than an eighth of a lane's fair share; at least min_samples samples each, at most
+// max_parts, only the first max_split pixels (the most expensive ones) and only when splittable.
+RT_DEV uint32_t plan_parts(uint32_t key, unsigned long long total, uint32_t lanes, uint32_t i, uint32_t max_split, int samples,
+                           int splittable) {
+  if (!splittable || i >= max_split || total == 0ull) return 1u;
+  const unsigned long long cost = 4095u - key;
+  unsigned long long parts = (cost * 8ull * lanes + total - 1ull) / total;
+  const unsigned long long most = (unsigned long long)max(samples / 8, 1);
+  parts = parts < 1ull ? 1ull : parts;
+  parts = parts > 32ull ? 32ull : parts;
+  parts = parts > most ? most : parts;
+  return (uint32_t)parts;
+}
+
+__global__ __launch_bounds__(256) void rt_plan_count_kernel(const uint32_t* keys, uint32_t n, const unsigned long long* total,
+                                                           uint32_t lanes, uint32_t max_split, int samples, int splittable,
+                                                           uint32_t* parts) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) parts[i] = plan_parts(keys[i], *total, lanes, i, max_split, samples, splittable);
+}
+
+// first[i] = exclusive prefix sum of parts.  Writes the jobs of pixel i and, from the last pixel, the job count.
+__global__ __launch_bounds__(256) void rt_plan_jobs_kernel(const uint32_t* order, const uint32_t* parts, const uint32_t* first,
+                                                          uint32_t n, int sample_begin, int sample_end, uint4* jobs,
+                                                          uint32_t* n_jobs) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t k = parts[i], base = first[i];
+  const int samples = sample_end - sample_begin;
+  for (uint32_t j = 0; j < k; j++) {
+    const int s0 = sample_begin + (int)(((long long)samples * j) / k);
+    const int s1 = sample_begin + (int)(((long long)samples * (j + 1)) / k);
+    jobs[base + j] = make_uint4(order[i], (uint32_t)s0, (uint32_t)s1, k > 1 ? i : RT_JOB_WHOLE);
+  }
+  if (i == n - 1) *n_jobs = base + k;
+}
+
+// Pixels that were cut into several jobs: the samples are added in sample order onto the sum the
+// probe pass carried, exactly as one lane would have added them.
+__global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order, const uint32_t* parts, uint32_t n_candidates,
+                                                          const float* carry_colour, const float* split_samples, int samples,
+                                                          int tile_x0, int tile_y0, int tile_w, int width, float* accum) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_candidates || parts[i] <= 1u) return;
+  const uint32_t rect_pixel = order[i];
+  f3 colour = mk3(carry_colour[3 * (size_t)rect_pixel], carry_colour[3 * (size_t)rect_pixel + 1], carry_colour[3 * (size_t)rect_pixel + 2]);
+  const float* src = split_samples + (size_t)i * (size_t)samples * 3;
+  for (int s = 0; s < samples; s++) colour = colour + mk3(src[3 * s], src[3 * s + 1], src[3 * s + 2]);
+  const int x = tile_x0 + (int)(rect_pixel % (uint32_t)tile_w), y = tile_y0 + (int)(rect_pixel / (uint32_t)tile_w);
+  float* dst = accum + 3 * ((size_t)y * (size_t)width + (size_t)x);
+  dst[0] = colour.x;
+  dst[1] = colour.y;
+  dst[2] = colour.z;
 }
 
 struct trace_args {

@@ -210,6 +210,11 @@ RT_DEV void hit_linear(const float4* sph, int n, f3 o, f3 d, float& t_out, int& 
 // index order), a NaN root, a traversal stack overflow — set `redo`, and the
 // ray is repeated with the scan.
 // ---------------------------------------------------------------------------
+// Nodes copied into LDS sit 144 bytes apart, not 128: every lane reads its own
+// node, and at 128 bytes the same field of any two nodes falls on one of only
+// two bank groups (up to 8-way conflicts per 16-lane group); 144 = 36 banks
+// spreads sixteen consecutive node numbers over sixteen different groups.
+#define RT_LDS_NODE_STRIDE 144
 #define RT_PAD_SCALE 1.25e-3f
 #define RT_T_FLOOR 0.000999f
 
@@ -399,7 +404,7 @@ struct tree_search {
   }
 
   RT_DEV void step_node(const scene_view& sv, trav_stack<PACKED> stk, lane_counters& k) {
-    const bvh4_node* nd = sv.nodes + cur;
+    const unsigned char* nd = reinterpret_cast<const unsigned char*>(sv.nodes) + (size_t)cur * (PACKED ? RT_LDS_NODE_STRIDE : sizeof(bvh4_node));
     const float4 lox = reinterpret_cast<const float4*>(nd)[0];
     const float4 loy = reinterpret_cast<const float4*>(nd)[1];
     const float4 loz = reinterpret_cast<const float4*>(nd)[2];

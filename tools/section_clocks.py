@@ -24,6 +24,8 @@ for n, k in zip(names[:-1], keys[:-1]):
     acc += c[k]
     print(f"  {n:24s} {100.0*c[k]/total:6.2f} %")
 print(f"  {'vote / loop overhead':24s} {100.0*(total-acc)/total:6.2f} %")
+span, waves = c["disk_tries"], c["limit_hits"]
+print(f"  longest wave {span/1e6:.1f} M ticks; mean over {waves} waves {total/waves/1e6:.1f} M ticks = {100.0*total/waves/span:.1f} % of the longest (run with RT_TWO_PASS=0)")
 tw, tl, pw, pl = c["trav_wave_steps"], c["trav_lane_steps"], c["path_wave_phases"], c["path_lane_phases"]
 print(f"  trav: {tw/1e6:.1f}M wave-steps, lanes/step={tl/max(tw,1):.1f}; path: {pw/1e6:.1f}M wave-phases, lanes/phase={pl/max(pw,1):.1f}")
 if tw: print(f"  ticks per trav wave-step {c['hits']/tw:.1f}; per path wave-phase {(c['sky']+c['lambertian']+c['metallic']+c['dialectric']+c['perlin'])/pw:.1f}")

@@ -7,6 +7,9 @@ for n in $names; do
   python3 - $out/$n.json $n <<'PY'
 import json, sys
 j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(sys.argv[2], "value", round(j["value"], 1), j["unit"], "kernel_ms", round(j["roofline"]["kernel_ms"], 2), "frac", round(j["roofline"]["frac"], 4))
+c = j["counters_per_launch"]
+print(sys.argv[2], "value", round(j["value"], 1), j["unit"], "kernel_ms", round(j["roofline"]["kernel_ms"], 2), "frac", round(j["roofline"]["frac"], 4),
+      "segments %.3fG node steps %.1fM path phases %.1fM ns/segment %.4f" % (c["segments"] / 1e9, c["trav_wave_steps"] / 1e6, c["path_wave_phases"] / 1e6,
+                                                                  j["roofline"]["kernel_ms"] * 1e6 / max(c["segments"], 1)))
 PY
 done
