@@ -334,6 +334,17 @@ int leaf_vote() {
   return v;
 }
 
+// How finely the main pass of two-pass rendering cuts expensive pixels: no job should exceed
+// 1/fineness of what a lane does on average (RT_SPLIT_FINENESS overrides, for tuning).
+int split_fineness() {
+  static int v = [] {
+    const char* e = getenv("RT_SPLIT_FINENESS");
+    int x = e ? atoi(e) : 16;
+    return x < 1 ? 1 : (x > 256 ? 256 : x);
+  }();
+  return v;
+}
+
 // Samples per pixel of the cost-probe pass, and the switch for two-pass
 // rendering (RT_TWO_PASS=0 in the environment turns it off, for comparison).
 constexpr int kProbeSamples = 16;
@@ -553,7 +564,8 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       // samples and cannot start in the middle).
       const int main_begin = p->sample_begin + kProbeSamples, main_samples = p->sample_end - main_begin;
       const uint32_t n = (uint32_t)n_rect;
-      const uint32_t lanes = (uint32_t)c->n_cu * 2048u;  // more than any launch keeps resident: jobs err on the small side
+      // a job should be a small fraction (1 / split_fineness()) of a lane's fair share of the frame
+      const uint32_t lanes = (uint32_t)c->n_cu * 1024u * (uint32_t)split_fineness();
       size_t want = kSplitBudgetBytes / ((size_t)main_samples * 3 * sizeof(float));
       const uint32_t max_split = (uint32_t)(want > 65536 ? 65536 : want);
       const int splittable = p->rng_mode == RT_RNG_COUNTER && max_split > 0 ? 1 : 0;
@@ -561,7 +573,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       HIP_TRY(c->plan_first.resize(n));
       HIP_TRY(c->plan_counts.resize(1));
       HIP_TRY(c->plan_total.resize(1));
-      HIP_TRY(c->plan_jobs.resize((size_t)n + 8ull * lanes + 64));
+      HIP_TRY(c->plan_jobs.resize((size_t)n + (size_t)lanes + 64));
       if (splittable) HIP_TRY(c->split_samples.resize((size_t)max_split * (size_t)main_samples * 3));
       size_t scan_bytes = 0;
       HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, c->plan_parts.p, c->plan_first.p, 0u, n, rocprim::plus<uint32_t>(), c->stream));

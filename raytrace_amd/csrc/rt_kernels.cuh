@@ -531,10 +531,10 @@ RT_DEV uint32_t plan_parts(uint32_t key, unsigned long long total, uint32_t lane
                            int splittable) {
   if (!splittable || i >= max_split || total == 0ull) return 1u;
   const unsigned long long cost = 4095u - key;
-  unsigned long long parts = (cost * 8ull * lanes + total - 1ull) / total;
+  unsigned long long parts = (cost * lanes + total - 1ull) / total;  // `lanes` arrives multiplied by the fineness factor
   const unsigned long long most = (unsigned long long)max(samples / 8, 1);
   parts = parts < 1ull ? 1ull : parts;
-  parts = parts > 32ull ? 32ull : parts;
+  parts = parts > 64ull ? 64ull : parts;
   parts = parts > most ? most : parts;
   return (uint32_t)parts;
 }
