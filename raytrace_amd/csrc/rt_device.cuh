@@ -109,21 +109,27 @@ struct lane_counters {
 // index before every try.
 template <int RNG, bool COUNTED>
 RT_DEV f3 random_unit_vector(uint32_t& a, lane_counters& k) {
+  // The accepted candidate is normalised after the loop, once for the whole wave: inside the
+  // loop the square root and the divide would be issued again in every iteration in which some
+  // lane accepts.
   uint32_t i = 0u;
+  f3 p;
+  float lensq;
   while (true) {
     a += i;
     float x = rng_float<RNG>(a);
     float y = rng_float<RNG>(a);
     float z = rng_float<RNG>(a);
-    f3 p = mk3(x, y, z);
-    float lensq = dot3(p, p);
+    p = mk3(x, y, z);
+    lensq = dot3(p, p);
     RT_COUNT(k, unit_tries, 1);
 #ifdef RT_ABL_ONE_TRY  // timing experiments only: wrong results
-    return div3(p, sqrtf(lensq));
+    break;
 #endif
-    if (0.0f < lensq && lensq <= 1.0f) return div3(p, sqrtf(lensq));
+    if (0.0f < lensq && lensq <= 1.0f) break;
     i += 1u;
   }
+  return div3(p, sqrtf(lensq));
 }
 
 // testFragment.fs:368-383: point of the unit quarter-disk, not normalised.
