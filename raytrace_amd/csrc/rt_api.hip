@@ -106,7 +106,7 @@ struct rt_ctx {
   dev_buf<float> leaf_r;
   dev_buf<int32_t> leaf_idx;
   float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
-  float r_max = 0.0f, r_median = 0.0f, abs_max = 0.0f;
+  float r_max = 0.0f, r_min = 0.0f, r_median = 0.0f, abs_max = 0.0f;
 
   // accumulator
   dev_buf<float> accum_own;
@@ -156,6 +156,7 @@ struct rt_ctx {
       s.root_hi[a] = root_hi[a];
     }
     s.r_max = r_max;
+    s.r_min = r_min;
     s.abs_max = abs_max;
     s.ovf = nullptr;
     s.ovf_cap = 0;
@@ -180,12 +181,12 @@ int build_lbvh(rt_ctx* c) {
   dev_buf<uint32_t> bounds, codes, codes_sorted, index, index_sorted;
   dev_buf<int> child0, child1, node_parent, leaf_parent, scalars, slot_of;
   dev_buf<unsigned int> arrivals;
-  dev_buf<float> node_box;
+  dev_buf<float> node_box, node_rmin;
   dev_buf<unsigned char> temp;
   auto cleanup = [&]() {
     bounds.release(); codes.release(); codes_sorted.release(); index.release(); index_sorted.release();
     child0.release(); child1.release(); node_parent.release(); leaf_parent.release(); scalars.release();
-    slot_of.release(); arrivals.release(); node_box.release(); temp.release();
+    slot_of.release(); arrivals.release(); node_box.release(); node_rmin.release(); temp.release();
   };
 #define BUILD_TRY(expr)                                                                       \
   do {                                                                                        \
@@ -210,6 +211,7 @@ int build_lbvh(rt_ctx* c) {
   BUILD_TRY(slot_of.resize(ni));
   BUILD_TRY(arrivals.resize(ni));
   BUILD_TRY(node_box.resize(6 * ni));
+  BUILD_TRY(node_rmin.resize(ni));
   size_t temp_bytes = 0;
   BUILD_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, codes.p, codes_sorted.p, index.p, index_sorted.p, nn, 0, 30,
                                       c->stream));
@@ -234,10 +236,10 @@ int build_lbvh(rt_ctx* c) {
   if (n > 1) {
     lbvh_hierarchy_kernel<<<blocks_i, 256, 0, st>>>(codes_sorted.p, n, child0.p, child1.p, node_parent.p, leaf_parent.p);
     lbvh_fit_kernel<<<blocks_n, 256, 0, st>>>(c->leaf_sph.p, c->leaf_r.p, n, child0.p, child1.p, node_parent.p,
-                                              leaf_parent.p, node_box.p, arrivals.p, scalars.p);
+                                              leaf_parent.p, node_box.p, node_rmin.p, arrivals.p, scalars.p);
     lbvh_mark_kernel<<<blocks_i, 256, 0, st>>>(n - 1, node_parent.p, slot_of.p, scalars.p + 1);
     lbvh_collapse_kernel<<<blocks_i, 256, 0, st>>>(c->leaf_sph.p, c->leaf_r.p, n - 1, child0.p, child1.p, node_box.p,
-                                                   slot_of.p, c->nodes.p);
+                                                   node_rmin.p, slot_of.p, c->nodes.p);
   }
   BUILD_TRY(hipGetLastError());
   BUILD_TRY(hipEventRecord(c->ev_b1, st));
@@ -289,9 +291,10 @@ int choose_search(const rt_ctx* c) {
   bool pad_ray = true;
   if (c->n_leaf > 0) {
     // One pad per ray is worth it when the worst pad (ray origin about one
-    // scene extent away) stays below the typical radius.
+    // scene extent away, smallest sphere of the tree) stays below the typical radius.
     const float extent = (c->root_hi[0] - c->root_lo[0]) + (c->root_hi[1] - c->root_lo[1]) + (c->root_hi[2] - c->root_lo[2]);
-    pad_ray = RT_PAD_SCALE * extent < c->r_median;
+    const float worst = std::sqrt(c->r_min * c->r_min + RT_PAD_K * extent * extent) - c->r_min;
+    pad_ray = worst < c->r_median;
   }
   // tree + hit-record + material arrays must leave room for the stacks of 16 waves
   const bool lds = c->n_nodes <= 4096 && search_lds_bytes<SEARCH_TREE_LDS_RAY>(n) <= kMaxLdsBytes - 4096;
@@ -726,7 +729,8 @@ int rt_scene_upload(rt_ctx* c, const void* spheres_std140, int n_spheres, const 
   std::vector<float4> big_sph, tree_sph;
   std::vector<int32_t> big_idx, tree_orig;
   std::vector<float> tree_r;
-  c->r_max = c->r_median = 0.0f;
+  c->r_max = c->r_median = c->r_min = 0.0f;
+  float r_min = 3.0e38f;
   if (accel == RT_ACCEL_LBVH && ns > 0) {
     std::vector<float> absr(ns);
     for (size_t i = 0; i < ns; i++) absr[i] = std::fabs(radius[i]);
@@ -754,11 +758,13 @@ int rt_scene_upload(rt_ctx* c, const void* spheres_std140, int n_spheres, const 
         tree_orig.push_back((int32_t)i);
         tree_abs.push_back(absr[i]);
         c->r_max = std::fmax(c->r_max, absr[i]);
+        r_min = std::fmin(r_min, absr[i]);
       }
     }
     if (!tree_abs.empty()) {
       std::nth_element(tree_abs.begin(), tree_abs.begin() + tree_abs.size() / 2, tree_abs.end());
       c->r_median = tree_abs[tree_abs.size() / 2];
+      c->r_min = r_min;
     }
   }
   HIP_TRY(c->big_sph.upload(big_sph, c->stream));

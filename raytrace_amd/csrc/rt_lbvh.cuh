@@ -139,11 +139,13 @@ __global__ __launch_bounds__(256) void lbvh_gather_kernel(const float4* sph, con
 
 // One thread per leaf climbs towards the root; at each node the first arrival
 // stops and the second one — which knows both children are finished — forms
-// the node's box.  node_box: 6 floats per internal node.  max_depth receives
-// the largest number of ancestors of any leaf.
+// the node's box and the smallest radius below it.  node_box: 6 floats per
+// internal node; node_rmin: one.  max_depth receives the largest number of
+// ancestors of any leaf.
 __global__ __launch_bounds__(256) void lbvh_fit_kernel(const float4* leaf_sph, const float* leaf_r, int n, const int* child0,
                                                        const int* child1, const int* node_parent, const int* leaf_parent,
-                                                       float* node_box, unsigned int* arrivals, int* max_depth) {
+                                                       float* node_box, float* node_rmin, unsigned int* arrivals,
+                                                       int* max_depth) {
   const int kpos = blockIdx.x * 256 + threadIdx.x;
   if (kpos >= n) return;
   // depth of this leaf (independent of the fitting order)
@@ -157,13 +159,16 @@ __global__ __launch_bounds__(256) void lbvh_fit_kernel(const float4* leaf_sph, c
     if (old == 0u) return;  // the sibling subtree is not finished yet
     __threadfence();        // see the boxes the sibling's thread published
     box3 b;
+    float rmin = __builtin_inff();
 #pragma unroll
     for (int side = 0; side < 2; side++) {
       const int c = side == 0 ? child0[cur] : child1[cur];
       box3 cb;
       if (c < 0) {
         cb = sphere_box(leaf_sph, leaf_r, ~c);
+        rmin = fminf(rmin, fabsf(leaf_r[~c]));
       } else {
+        rmin = fminf(rmin, __hip_atomic_load(node_rmin + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         const float* src = node_box + 6 * (size_t)c;
 #pragma unroll
         for (int a = 0; a < 3; a++) {
@@ -187,6 +192,7 @@ __global__ __launch_bounds__(256) void lbvh_fit_kernel(const float4* leaf_sph, c
       __hip_atomic_store(dst + a, b.lo[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(dst + 3 + a, b.hi[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __hip_atomic_store(node_rmin + cur, rmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence();  // publish before announcing arrival at the parent
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     cur = node_parent[cur];
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(256) void lbvh_mark_kernel(int n_internal, const in
 
 __global__ __launch_bounds__(256) void lbvh_collapse_kernel(const float4* leaf_sph, const float* leaf_r, int n_internal,
                                                             const int* child0, const int* child1, const float* node_box,
-                                                            const int* slot_of, bvh4_node* nodes) {
+                                                            const float* node_rmin, const int* slot_of, bvh4_node* nodes) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_internal) return;
   const int slot = slot_of[i];
@@ -231,14 +237,16 @@ __global__ __launch_bounds__(256) void lbvh_collapse_kernel(const float4* leaf_s
   bvh4_node nd;
 #pragma unroll
   for (int s = 0; s < 4; s++) {
-    nd.pad[s] = 0;
+    nd.rmin[s] = 0.0f;
     if (s < nk) {
       const int c = kids[s];
       box3 b;
       if (c < 0) {
         b = sphere_box(leaf_sph, leaf_r, ~c);
         nd.ref[s] = c;
+        nd.rmin[s] = fabsf(leaf_r[~c]);
       } else {
+        nd.rmin[s] = node_rmin[c];
 #pragma unroll
         for (int a = 0; a < 3; a++) {
           b.lo[a] = node_box[6 * (size_t)c + a];

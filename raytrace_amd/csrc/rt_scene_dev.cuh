@@ -8,13 +8,14 @@
 // the boxes of up to four children, component-wise so that one 16-byte load
 // brings the same plane of all four, and their references.
 // ref >= 0: child node index; RT_REF_EMPTY: unused slot; otherwise a leaf,
-// ~ref = position of the sphere in Morton order.  128 bytes.
+// ~ref = position of the sphere in Morton order.  rmin: the smallest radius among
+// the spheres below each child (the box-growing rule needs it).  128 bytes.
 #define RT_REF_EMPTY ((int32_t)0x80000000)
 struct __attribute__((aligned(16))) bvh4_node {
   float lox[4], loy[4], loz[4];
   float hix[4], hiy[4], hiz[4];
   int32_t ref[4];
-  int32_t pad[4];
+  float rmin[4];
 };
 
 struct scene_dev {
@@ -39,6 +40,7 @@ struct scene_dev {
   int32_t root;             // reference of the root (a leaf reference when n_leaf == 1)
   float root_lo[3], root_hi[3];  // bounds of the tree's spheres
   float r_max;              // largest radius in the tree
+  float r_min;              // smallest radius in the tree
   float abs_max;            // largest |coordinate| sum of the root box corners
   // Trees read from HBM keep only the top of each lane's traversal stack in
   // LDS; deeper entries go to this per-launch buffer (ovf_cap entries per lane,
@@ -186,20 +188,29 @@ RT_DEV void hit_linear(const float4* sph, int n, f3 o, f3 d, float& t_out, int& 
 // that exist only because of binary32 rounding in the sphere test: the computed
 // discriminant differs from the exact one by at most a*(19u*|oc|^2 + 6u*r^2),
 // u = 2^-24, so a ray can "hit" a sphere whose true distance from the ray is up
-// to sqrt(r^2 + 19u(|oc|^2 + r^2)) <= r + S0*(|oc| + r), S0 = sqrt(19u) =
-// 1.064e-3.  Boxes are therefore grown by  pad = S*D,  S = 1.25e-3, where D
-// bounds |oc| + r of every sphere the ray could still accept; the slack S - S0
-// also covers the rounding of the computed t (a few u relative).  Two rules:
+// to sqrt(r^2 + E0), E0 = 19u*(|oc|^2 + r^2), and the point at the computed
+// parameter lies within that same distance of the centre.  Boxes (which hold
+// centre +- r of every sphere inside) are therefore grown by
+//     pad = sqrt(rmin^2 + K*D^2) - rmin + L*D1,   K = 1.5625e-6 (1.38 * 19u),  L = 1e-6
+// where D is the Euclidean distance from the ray origin to the farthest corner
+// of the box (>= |oc| + r of every sphere the ray could still accept), D1 the
+// same in the L1 norm, and rmin a lower bound of the radii inside: sqrt(r^2 + E)
+// - r decreases with r, so a box of larger spheres needs far less than the
+// worst case sqrt(K)*D = 1.25e-3*D of a vanishing one.  The slack K - 19u
+// covers the rounding of h and of the computed t (a few u*D in position, i.e. a
+// few u*D*(r + sqrt(E)) in squared distance); the linear term covers the 1-ulp
+// hardware square root, the cancellation in sqrt(..) - rmin and the slab
+// arithmetic.  Two rules:
 //
-//   PAD_RAY   one pad per ray: D = min(L1 distance from the origin to the
-//             farthest corner of the tree's bounds, 1.003*(best_t*|d| + 2*r_max))
-//             once a hit at best_t is known.  The slab test is six FMAs on
-//             per-ray constants; their cancellation error (u * |coordinate|)
-//             is covered by an extra 2^-22 * (|o|_1 + abs_max) in the pad.
-//             Good when the tree's extent is small against its spheres.
-//   PAD_NODE  one pad per box: D = L1 distance from the origin to that box's
-//             farthest corner.  Costs about twice the arithmetic per box but
-//             stays tight for near boxes in a sparse, wide scene.
+//   PAD_RAY   one pad per ray: D from the tree's bounds, cut down to
+//             1.003*(best_t*|d| + 2*r_max) once a hit at best_t is known; rmin
+//             of the whole tree.  The slab test is six FMAs on per-ray
+//             constants; their cancellation error (u * |coordinate|) is
+//             covered by an extra 2^-22 * (|o|_1 + abs_max) in the pad.  Good
+//             when the tree's extent is small against its spheres.
+//   PAD_NODE  one pad per box: D to that box's farthest corner, rmin of the
+//             spheres below it.  More arithmetic per box, but tight for near
+//             boxes in a sparse, wide scene.
 //
 // A box is skipped only when the ray misses the grown box, when the grown box
 // lies entirely before t = 0.001, or when it starts beyond the closest hit.
@@ -215,7 +226,9 @@ RT_DEV void hit_linear(const float4* sph, int n, f3 o, f3 d, float& t_out, int& 
 // two bank groups (up to 8-way conflicts per 16-lane group); 144 = 36 banks
 // spreads sixteen consecutive node numbers over sixteen different groups.
 #define RT_LDS_NODE_STRIDE 144
-#define RT_PAD_SCALE 1.25e-3f
+#define RT_PAD_SCALE 1.25e-3f   // sqrt(RT_PAD_K): the pad per unit distance of a vanishing sphere
+#define RT_PAD_K 1.5625e-6f
+#define RT_PAD_LIN 1.0e-6f
 #define RT_T_FLOOR 0.000999f
 
 struct trav_candidate {
@@ -241,30 +254,69 @@ RT_DEV void consider_sphere(float4 s, int upload_index, f3 o, f3 d, float a, tra
 }
 
 // Per-ray constants of the PAD_RAY slab test: t_lo = lo*inv_d + k_lo, t_hi = hi*inv_d + k_hi.
+// With SELECT (nodes in LDS) the planes are picked by the sign of the direction instead of by
+// min / max of the two parameters: k_lo then holds the constant of the plane the ray enters by,
+// k_hi that of the plane it leaves by, and `sel` holds, one byte per axis, 48 where the direction
+// is negative (the distance in bytes from a node's lo plane to its hi plane) and 0 elsewhere.
 struct slab_consts {
   f3 inv_d, k_lo, k_hi;
+  uint32_t sel;
 };
 
 RT_DEV float slab_dir(float v) { return fabsf(v) < 1e-20f ? copysignf(1e-20f, v) : v; }
 
-RT_DEV float far_corner_l1(const float* lo, const float* hi, f3 o) {
-  return (fmaxf(o.x - lo[0], hi[0] - o.x) + fmaxf(o.y - lo[1], hi[1] - o.y)) + fmaxf(o.z - lo[2], hi[2] - o.z);
+// Growth of a box whose farthest corner lies mx, my, mz away along the axes and whose spheres
+// have radii of at least rmin.  FMAs are fine here: box tests decide what is visited, never a value.
+RT_DEV float box_pad(float mx, float my, float mz, float rmin) {
+  const float d2 = __builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx));
+  const float s = __builtin_amdgcn_sqrtf(__builtin_fmaf(RT_PAD_K, d2, rmin * rmin));
+  return __builtin_fmaf(RT_PAD_LIN, (mx + my) + mz, s - rmin);
 }
 
+template <bool SELECT>
 RT_DEV void make_slab_consts(const scene_dev& sc, f3 o, f3 inv_d, float a, const trav_candidate& c, slab_consts& s) {
-  float D = far_corner_l1(sc.root_lo, sc.root_hi, o);
-  // |d| from the 1-ulp hardware sqrt: the 1.003 factor absorbs it
-  if (c.best_i >= 0) D = fminf(D, 1.003f * (c.best_t * __builtin_amdgcn_sqrtf(a) + 2.0f * sc.r_max));
-  const float pad = RT_PAD_SCALE * D + 2.384186e-7f * ((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z) + sc.abs_max);
+  const float mx = fmaxf(o.x - sc.root_lo[0], sc.root_hi[0] - o.x), my = fmaxf(o.y - sc.root_lo[1], sc.root_hi[1] - o.y),
+              mz = fmaxf(o.z - sc.root_lo[2], sc.root_hi[2] - o.z);
+  float d2 = __builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx));
+  if (c.best_i >= 0) {
+    // nothing farther than the hit can still be accepted; |d| from the 1-ulp hardware sqrt: the
+    // 1.003 factor absorbs it
+    const float reach = 1.003f * (c.best_t * __builtin_amdgcn_sqrtf(a) + 2.0f * sc.r_max);
+    d2 = fminf(d2, reach * reach);
+  }
+  // the L1 distance of the linear term is at most sqrt(3) times the Euclidean one
+  const float grow = (__builtin_amdgcn_sqrtf(__builtin_fmaf(RT_PAD_K, d2, sc.r_min * sc.r_min)) - sc.r_min) +
+                     1.7321f * RT_PAD_LIN * __builtin_amdgcn_sqrtf(d2);
+  const float pad = grow + 2.384186e-7f * ((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z) + sc.abs_max);
   s.inv_d = inv_d;
   s.k_lo = mk3(-(o.x + pad) * inv_d.x, -(o.y + pad) * inv_d.y, -(o.z + pad) * inv_d.z);
   s.k_hi = mk3(-(o.x - pad) * inv_d.x, -(o.y - pad) * inv_d.y, -(o.z - pad) * inv_d.z);
+  s.sel = 0u;
+  if (SELECT) {
+    // fma is monotonic in each argument and lo <= hi, k_lo <= k_hi for a positive inv_d (the
+    // reverse for a negative one): the selected parameters are bit for bit the min and the max
+    const bool nx = inv_d.x < 0.0f, ny = inv_d.y < 0.0f, nz = inv_d.z < 0.0f;
+    const f3 lo = s.k_lo, hi = s.k_hi;
+    s.k_lo = mk3(nx ? hi.x : lo.x, ny ? hi.y : lo.y, nz ? hi.z : lo.z);
+    s.k_hi = mk3(nx ? lo.x : hi.x, ny ? lo.y : hi.y, nz ? lo.z : hi.z);
+    s.sel = (nx ? 48u : 0u) | (ny ? 48u << 8 : 0u) | (nz ? 48u << 16 : 0u);
+  }
+}
+
+// The same interval from the entry and exit planes of a child (SELECT, see slab_consts).
+RT_DEV void child_interval_selected(float nx, float ny, float nz, float fx, float fy, float fz, const slab_consts& s, float limit,
+                                    float& tn, float& tf) {
+  const float t0x = __builtin_fmaf(nx, s.inv_d.x, s.k_lo.x), t1x = __builtin_fmaf(fx, s.inv_d.x, s.k_hi.x);
+  const float t0y = __builtin_fmaf(ny, s.inv_d.y, s.k_lo.y), t1y = __builtin_fmaf(fy, s.inv_d.y, s.k_hi.y);
+  const float t0z = __builtin_fmaf(nz, s.inv_d.z, s.k_lo.z), t1z = __builtin_fmaf(fz, s.inv_d.z, s.k_hi.z);
+  tn = fmaxf(fmaxf(fmaxf(t0x, t0y), t0z), RT_T_FLOOR);
+  tf = fminf(fminf(fminf(t1x, t1y), t1z), limit);
 }
 
 // Parameter interval of the ray inside the grown box of one child, clipped to
 // [RT_T_FLOOR, limit]: the child is worth visiting iff tn <= tf.
 template <bool PAD_RAY>
-RT_DEV void child_interval(float lx, float ly, float lz, float hx, float hy, float hz, f3 o, const slab_consts& s,
+RT_DEV void child_interval(float lx, float ly, float lz, float hx, float hy, float hz, float rmin, f3 o, const slab_consts& s,
                            float limit, float& tn, float& tf) {
   float t0x, t1x, t0y, t1y, t0z, t1z;
   if (PAD_RAY) {
@@ -273,7 +325,7 @@ RT_DEV void child_interval(float lx, float ly, float lz, float hx, float hy, flo
     t0z = __builtin_fmaf(lz, s.inv_d.z, s.k_lo.z); t1z = __builtin_fmaf(hz, s.inv_d.z, s.k_hi.z);
   } else {
     const float ax = lx - o.x, bx = hx - o.x, ay = ly - o.y, by = hy - o.y, az = lz - o.z, bz = hz - o.z;
-    const float pad = RT_PAD_SCALE * ((fmaxf(-ax, bx) + fmaxf(-ay, by)) + fmaxf(-az, bz));
+    const float pad = box_pad(fmaxf(-ax, bx), fmaxf(-ay, by), fmaxf(-az, bz), rmin);
     t0x = (ax - pad) * s.inv_d.x; t1x = (bx + pad) * s.inv_d.x;
     t0y = (ay - pad) * s.inv_d.y; t1y = (by + pad) * s.inv_d.y;
     t0z = (az - pad) * s.inv_d.z; t1z = (bz + pad) * s.inv_d.z;
@@ -360,6 +412,7 @@ struct tree_search {
   trav_candidate c;
   int cur, sp;  // cur: node to test next, -1 when the stack has run dry
   static constexpr bool LEAF_INLINE = PACKED;
+  static constexpr bool SELECT = PAD_RAY && PACKED;  // planes picked by direction sign (slab_consts)
   leaf_queue<PACKED> lq;
 
   RT_DEV bool has_node() const { return cur >= 0; }
@@ -389,7 +442,7 @@ struct tree_search {
     // that flat is inside or outside the slab for its whole length either way).
     sl.inv_d = mk3(__builtin_amdgcn_rcpf(slab_dir(d.x)), __builtin_amdgcn_rcpf(slab_dir(d.y)),
                    __builtin_amdgcn_rcpf(slab_dir(d.z)));
-    if (PAD_RAY) make_slab_consts(sc, o, sl.inv_d, a, c, sl);
+    if (PAD_RAY) make_slab_consts<SELECT>(sc, o, sl.inv_d, a, c, sl);
     if (sc.root < 0) {  // a single sphere in the tree
       consider_sphere<COUNTED>(sv.leaf_sph[~sc.root], sv.leaf_idx[~sc.root], o, d, a, c, k);
       return false;
@@ -405,19 +458,35 @@ struct tree_search {
 
   RT_DEV void step_node(const scene_view& sv, trav_stack<PACKED> stk, lane_counters& k) {
     const unsigned char* nd = reinterpret_cast<const unsigned char*>(sv.nodes) + (size_t)cur * (PACKED ? RT_LDS_NODE_STRIDE : sizeof(bvh4_node));
-    const float4 lox = reinterpret_cast<const float4*>(nd)[0];
-    const float4 loy = reinterpret_cast<const float4*>(nd)[1];
-    const float4 loz = reinterpret_cast<const float4*>(nd)[2];
-    const float4 hix = reinterpret_cast<const float4*>(nd)[3];
-    const float4 hiy = reinterpret_cast<const float4*>(nd)[4];
-    const float4 hiz = reinterpret_cast<const float4*>(nd)[5];
     const int4 ref = reinterpret_cast<const int4*>(nd)[6];
     const int refs[4] = {ref.x, ref.y, ref.z, ref.w};
     float tn[4], tf[4];
-    child_interval<PAD_RAY>(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, o, sl, c.best_t, tn[0], tf[0]);
-    child_interval<PAD_RAY>(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, o, sl, c.best_t, tn[1], tf[1]);
-    child_interval<PAD_RAY>(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, o, sl, c.best_t, tn[2], tf[2]);
-    child_interval<PAD_RAY>(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, o, sl, c.best_t, tn[3], tf[3]);
+    if (SELECT) {
+      const uint32_t sx = sl.sel & 0xFFu, sy = (sl.sel >> 8) & 0xFFu, sz = (sl.sel >> 16) & 0xFFu;
+      const float4 nx = *reinterpret_cast<const float4*>(nd + sx);
+      const float4 ny = *reinterpret_cast<const float4*>(nd + 16 + sy);
+      const float4 nz = *reinterpret_cast<const float4*>(nd + 32 + sz);
+      const float4 fx = *reinterpret_cast<const float4*>(nd + 48 - sx);
+      const float4 fy = *reinterpret_cast<const float4*>(nd + 64 - sy);
+      const float4 fz = *reinterpret_cast<const float4*>(nd + 80 - sz);
+      child_interval_selected(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, sl, c.best_t, tn[0], tf[0]);
+      child_interval_selected(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, sl, c.best_t, tn[1], tf[1]);
+      child_interval_selected(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, sl, c.best_t, tn[2], tf[2]);
+      child_interval_selected(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, sl, c.best_t, tn[3], tf[3]);
+    } else {
+      const float4 lox = reinterpret_cast<const float4*>(nd)[0];
+      const float4 loy = reinterpret_cast<const float4*>(nd)[1];
+      const float4 loz = reinterpret_cast<const float4*>(nd)[2];
+      const float4 hix = reinterpret_cast<const float4*>(nd)[3];
+      const float4 hiy = reinterpret_cast<const float4*>(nd)[4];
+      const float4 hiz = reinterpret_cast<const float4*>(nd)[5];
+      float4 rmin = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (!PAD_RAY) rmin = reinterpret_cast<const float4*>(nd)[7];
+      child_interval<PAD_RAY>(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, rmin.x, o, sl, c.best_t, tn[0], tf[0]);
+      child_interval<PAD_RAY>(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, rmin.y, o, sl, c.best_t, tn[1], tf[1]);
+      child_interval<PAD_RAY>(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, rmin.z, o, sl, c.best_t, tn[2], tf[2]);
+      child_interval<PAD_RAY>(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, rmin.w, o, sl, c.best_t, tn[3], tf[3]);
+    }
     bool ok[4];
     unsigned leaf_mask = 0;
 #pragma unroll
