@@ -157,6 +157,8 @@ struct rt_ctx {
     }
     s.r_max = r_max;
     s.r_min = r_min;
+    s.ref_mask = 0xFFFu;
+    while (s.ref_mask + 1u < (uint32_t)(n_nodes > 0 ? n_nodes : 1)) s.ref_mask = s.ref_mask * 2u + 1u;
     s.abs_max = abs_max;
     s.ovf = nullptr;
     s.ovf_cap = 0;
@@ -396,7 +398,7 @@ hipError_t attach_overflow(rt_ctx* c, long long blocks, scene_dev& sc) {
   if (!T::tree || T::lds) return hipSuccess;
   const int cap = 3 * (c->depth / 2 + 2) - T::stack;
   if (cap <= 0) return hipSuccess;
-  hipError_t e = c->ovf.resize((size_t)blocks * T::waves * (size_t)cap * 128);
+  hipError_t e = c->ovf.resize((size_t)blocks * T::waves * (size_t)cap * 64);
   if (e != hipSuccess) return e;
   sc.ovf = c->ovf.p;
   sc.ovf_cap = cap;

@@ -21,7 +21,7 @@ enum {
 };
 
 #ifndef RT_TRACE_WAVES
-#define RT_TRACE_WAVES 5
+#define RT_TRACE_WAVES 4
 #endif
 #ifndef RT_LINEAR_WAVES
 #define RT_LINEAR_WAVES 4
@@ -36,8 +36,11 @@ struct search_traits {
   static constexpr int waves = lds ? 16 : 4;       // waves per workgroup
   static constexpr int threads = waves * 64;
   static constexpr int stack = lds ? 16 : 8;       // entries per lane kept in LDS
-  // per wave; the one-word stacks of LDS trees carry one more row, the sink of stores that must not land
-  static constexpr int stack_words = !tree ? 0 : (lds ? (stack + 1) * 64 : stack * 128);
+  // per wave: one word per entry and lane, and one more row, the sink of stores that must not land
+  static constexpr int stack_words = !tree ? 0 : (stack + 1) * 64;
+  // trees read from HBM pass their nodes through a per-wave staging area in LDS (stage_nodes)
+  static constexpr bool staged = tree && !lds;
+  static constexpr int stage_bytes = staged ? RT_STAGE_BYTES : 0;
   // Waves per SIMD the register allocation of the render kernel aims for.
   static constexpr int render_waves_per_simd = tree ? 4 : RT_LINEAR_WAVES;
   // The closest-hit kernel on an HBM-resident tree waits on node fetches: more waves hide more of them.
@@ -65,7 +68,7 @@ inline size_t search_scene_lds_bytes(const scene_counts& n) {
 template <int SEARCH>
 inline size_t search_lds_bytes(const scene_counts& n) {
   using T = search_traits<SEARCH>;
-  return search_scene_lds_bytes<SEARCH>(n) + (size_t)T::waves * T::stack_words * 4;
+  return search_scene_lds_bytes<SEARCH>(n) + (size_t)T::waves * ((size_t)T::stack_words * 4 + T::stage_bytes);
 }
 
 struct render_args {
@@ -116,7 +119,6 @@ RT_DEV void flush_counters(unsigned long long* g, const lane_counters& k) {
   }
 }
 
-extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds[];
 
 RT_DEV size_t pad16_dev(size_t b) { return (b + 15) & ~(size_t)15; }
 
@@ -125,7 +127,7 @@ RT_DEV size_t pad16_dev(size_t b) { return (b + 15) & ~(size_t)15; }
 // and copy the scene in.  Every thread of the workgroup must call this before
 // the first search.
 template <int SEARCH>
-RT_DEV void search_setup(const scene_dev& sc, scene_view& sv, uint32_t*& stack_col) {
+RT_DEV void search_setup(const scene_dev& sc, scene_view& sv, uint32_t*& stack_col, uint32_t& stage) {
   using T = search_traits<SEARCH>;
   sv.nodes = sc.nodes;
   sv.leaf_sph = sc.leaf_sph;
@@ -139,6 +141,7 @@ RT_DEV void search_setup(const scene_dev& sc, scene_view& sv, uint32_t*& stack_c
   sv.ovf_col = nullptr;
   sv.ovf_cap = 0;
   stack_col = nullptr;
+  stage = 0u;
   unsigned char* base = rt_lds;
   if (T::scan_lds) {
     float4* d = reinterpret_cast<float4*>(base);
@@ -175,8 +178,9 @@ RT_DEV void search_setup(const scene_dev& sc, scene_view& sv, uint32_t*& stack_c
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   stack_col = reinterpret_cast<uint32_t*>(base) + wave * T::stack_words + lane;
+  if (T::staged) stage = (uint32_t)(T::waves * T::stack_words * 4 + wave * T::stage_bytes);  // no scene copy precedes the stacks
   if (!T::lds && sc.ovf != nullptr) {
-    sv.ovf_col = sc.ovf + ((size_t)blockIdx.x * T::waves + wave) * (size_t)sc.ovf_cap * 128 + lane;
+    sv.ovf_col = sc.ovf + ((size_t)blockIdx.x * T::waves + wave) * (size_t)sc.ovf_cap * 64 + lane;
     sv.ovf_cap = sc.ovf_cap;
   }
 }
@@ -187,6 +191,7 @@ template <int SEARCH, bool COUNTED>
 struct searcher {
   using T = search_traits<SEARCH>;
   tree_search<T::pad_ray, T::lds, T::stack, COUNTED> ts;
+  uint32_t ref_mask;  // wave-uniform (scene_dev::ref_mask), set by the kernel before the first step
   RT_DEV bool begin(const scene_dev& sc, const scene_view& sv, f3 o, f3 d, lane_counters& k) {
     if (T::tree) return ts.begin(sc, sv, o, d, k);
     ts.o = o;
@@ -198,11 +203,13 @@ struct searcher {
   RT_DEV bool node_ready() const { return T::tree && ts.node_ready(); }
   RT_DEV bool has_leaf() const { return T::tree && ts.has_leaf(); }
   RT_DEV bool active() const { return T::tree && ts.active(); }
-  RT_DEV void step_node(const scene_view& sv, uint32_t* stack_col, lane_counters& k) {
+  RT_DEV void step_node(const scene_view& sv, uint32_t* stack_col, uint32_t staged, lane_counters& k) {
     trav_stack<T::lds> stk;
     stk.col = stack_col;
-    ts.step_node(sv, stk, k);
+    stk.mask = T::lds ? 0xFFFu : ref_mask;
+    ts.step_node(sv, stk, staged, k);
   }
+  RT_DEV int node_wanted() const { return ts.cur; }
   RT_DEV void step_leaf(const scene_view& sv, lane_counters& k) { ts.step_leaf(sv, k); }
   RT_DEV void finish(const scene_dev& sc, const scene_view& sv, float& t, int& idx, lane_counters& k) {
     ts.finish(sc, sv, t, idx, k);
@@ -284,7 +291,8 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
   const scene_dev& sc = A.sc;
   scene_view sv;
   uint32_t* stack_col;
-  search_setup<SEARCH>(sc, sv, stack_col);
+  uint32_t stage;  // this wave's node staging area (byte offset into LDS)
+  search_setup<SEARCH>(sc, sv, stack_col, stage);
 
   const int tw = P.tile_x1 - P.tile_x0, th = P.tile_y1 - P.tile_y0;
   const int tiles_x = (tw + 7) >> 3, tiles_y = (th + 7) >> 3;
@@ -299,6 +307,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
   const f3 ddv = mk3(P.defocus_disk_v[0], P.defocus_disk_v[1], P.defocus_disk_v[2]);
 
   searcher<SEARCH, COUNTED> srch;
+  srch.ref_mask = sc.ref_mask;
   bool have = false;        // this lane owns a pixel
   bool alive = false;       // a path of that pixel is in flight
   bool pending = false;     // a finished search waits to be shaded
@@ -358,7 +367,9 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       } else {
         RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
         RT_COUNT(k, trav_lane_steps, node_lane ? 1u : 0u);
-        if (node_lane) srch.step_node(sv, stack_col, k);
+        uint32_t staged = 0u;  // the whole wave fetches the nodes its lanes want
+        if (search_traits<SEARCH>::staged) staged = stage_nodes(sv.nodes, node_lane ? srch.node_wanted() : -1, stage);
+        if (node_lane) srch.step_node(sv, stack_col, staged, k);
       }
       if (in_trav) in_trav = srch.active();
       RT_CLK_STOP(0);
@@ -602,9 +613,11 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
   const scene_dev& sc = A.sc;
   scene_view sv;
   uint32_t* stack_col;
-  search_setup<SEARCH>(sc, sv, stack_col);
+  uint32_t stage;  // this wave's node staging area (byte offset into LDS)
+  search_setup<SEARCH>(sc, sv, stack_col, stage);
   lane_counters k = {};
   searcher<SEARCH, COUNTED> srch;
+  srch.ref_mask = sc.ref_mask;
   bool pending = false, in_trav = false, exhausted = false;
   size_t ray = 0;
   unsigned long long pool_next = 0, pool_end = 0;  // the wave's share of the ray queue
@@ -623,7 +636,9 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       } else {
         RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
         RT_COUNT(k, trav_lane_steps, node_lane ? 1u : 0u);
-        if (node_lane) srch.step_node(sv, stack_col, k);
+        uint32_t staged = 0u;  // the whole wave fetches the nodes its lanes want
+        if (search_traits<SEARCH>::staged) staged = stage_nodes(sv.nodes, node_lane ? srch.node_wanted() : -1, stage);
+        if (node_lane) srch.step_node(sv, stack_col, staged, k);
       }
       if (in_trav) in_trav = srch.active();
       continue;

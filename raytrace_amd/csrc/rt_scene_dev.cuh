@@ -41,6 +41,7 @@ struct scene_dev {
   float root_lo[3], root_hi[3];  // bounds of the tree's spheres
   float r_max;              // largest radius in the tree
   float r_min;              // smallest radius in the tree
+  uint32_t ref_mask;        // 2^k - 1 >= every 4-wide node index: the index bits of a traversal-stack entry
   float abs_max;            // largest |coordinate| sum of the root box corners
   // Trees read from HBM keep only the top of each lane's traversal stack in
   // LDS; deeper entries go to this per-launch buffer (ovf_cap entries per lane,
@@ -61,7 +62,7 @@ struct scene_view {
   const int32_t* sph_mat;
   const float4* mat_a;
   const int32_t* mat_type;
-  uint32_t* ovf_col;        // this lane's column of the stack overflow buffer: entry e at ovf_col[e * 128] (+64: parameter)
+  uint32_t* ovf_col;        // this lane's column of the stack overflow buffer: entry e at ovf_col[e * 64]
   int32_t ovf_cap;
 };
 
@@ -334,23 +335,83 @@ RT_DEV void child_interval(float lx, float ly, float lz, float hx, float hy, flo
   tf = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), limit);
 }
 
-// Traversal stack entry.  PACKED (trees of at most 4096 nodes): one word, the
-// entry parameter truncated to 20 bits above the 12-bit node index, so that
-// entries order by distance as unsigned integers.  Otherwise two words.
+// Node fetch for trees read from HBM.  A lane that loads its own 128-byte node with eight 16-byte
+// loads costs the CU's vector cache eight tag look-ups per lane, 512 per wave and step, and that
+// look-up rate (about one per clock) is what bounds an incoherent closest-hit batch.  So the first
+// RT_STAGE_PIECES 16-byte pieces of every node are fetched by a group of as many lanes together —
+// in pass p the lanes of a group read consecutive pieces of the node wanted by the group's lane p,
+// one request per node instead of one per piece — with loads that write LDS directly: row p of the
+// wave's staging area then holds, group after group, what the lanes p of the groups want.  The
+// remaining pieces each lane loads itself (staging whole nodes would need 8 KB of LDS per wave
+// and cost more in occupancy than it saves in look-ups).  Every lane of the wave must call this
+// (my_node < 0: nothing wanted); returns where the staged part of the lane's node lies.
+// The staging area and the returned place are byte offsets into the kernel's dynamic LDS.
+#ifndef RT_STAGE_PIECES
+#define RT_STAGE_PIECES 4
+#endif
+#ifndef RT_STAGE_DMA
+#define RT_STAGE_DMA 1
+#endif
+#define RT_STAGE_ROW 1040   // 64 lanes x 16 bytes + 16: the rows start in different banks
+#define RT_STAGE_BYTES (RT_STAGE_PIECES * RT_STAGE_ROW + 256)
+extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds[];
+RT_DEV uint32_t stage_nodes(const bvh4_node* nodes, int my_node, uint32_t stage_offset) {
+  constexpr int G = RT_STAGE_PIECES;  // lanes of a group = passes = staged pieces
+  static_assert(G == 4 || G == 8, "a group reads 64 or 128 consecutive bytes");
+  unsigned char* stage = rt_lds + stage_offset;
+  const int lane = threadIdx.x & 63, sub = lane & (G - 1);
+  int* wanted = reinterpret_cast<int*>(stage + G * RT_STAGE_ROW);
+  wanted[lane] = my_node;
+  __builtin_amdgcn_wave_barrier();  // LDS operations of one wave execute in order
+  int w[G];
+  {
+    const int4 w0 = *reinterpret_cast<const int4*>(wanted + (lane & ~(G - 1)));
+    w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w;
+    if (G == 8) {
+      const int4 w1 = *reinterpret_cast<const int4*>(wanted + (lane & ~(G - 1)) + 4);
+      w[G - 4] = w1.x; w[G - 3] = w1.y; w[G - 2] = w1.z; w[G - 1] = w1.w;
+    }
+  }
+  const unsigned char* base = reinterpret_cast<const unsigned char*>(nodes) + sub * 16;
+#if RT_STAGE_DMA
+  // loads that write LDS directly: each lane gives its own source address; the 64 x 16 bytes land
+  // side by side from the row start
+#pragma unroll
+  for (int p = 0; p < G; p++) {
+    if (w[p] >= 0)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)w[p] * sizeof(bvh4_node)),
+                                       (__attribute__((address_space(3))) void*)(stage + p * RT_STAGE_ROW), 16, 0, 0);
+  }
+#else
+  // through registers: all loads first (a pass nobody wants reads node 0), then the stores
+  float4 piece[G];
+#pragma unroll
+  for (int p = 0; p < G; p++) piece[p] = *reinterpret_cast<const float4*>(base + (size_t)max(w[p], 0) * sizeof(bvh4_node));
+#pragma unroll
+  for (int p = 0; p < G; p++) *reinterpret_cast<float4*>(stage + p * RT_STAGE_ROW + lane * 16) = piece[p];
+#endif
+  return stage_offset + (uint32_t)(sub * RT_STAGE_ROW + (lane / G) * (16 * G));
+}
+// Before the staged part is read.
+RT_DEV void stage_wait() {
+#if RT_STAGE_DMA
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Traversal stack entry: one word, the entry parameter (a positive float, so its bits order as
+// an unsigned integer) with its low bits replaced by the node index.  `mask` covers the index:
+// 12 bits for trees in LDS (at most 4096 nodes), as many as the node count needs otherwise.
+// The truncated parameter is never above the true one, which keeps "entry <= closest hit" a
+// conservative test; with fewer parameter bits the visiting order gets coarser, not the result.
 template <bool PACKED>
-struct trav_stack;
-
-template <>
-struct trav_stack<true> {
+struct trav_stack {
   uint32_t* col;  // this lane's column: element e at col[e * 64]
-  RT_DEV static uint32_t key(float tn, int ref) { return (__float_as_uint(tn) & 0xFFFFF000u) | (uint32_t)ref; }
-  RT_DEV static float key_tn(uint32_t k) { return __uint_as_float(k & 0xFFFFF000u); }
-  RT_DEV static int key_ref(uint32_t k) { return (int)(k & 0xFFFu); }
-};
-
-template <>
-struct trav_stack<false> {
-  uint32_t* col;  // refs at col[e * 128], entry parameters at col[e * 128 + 64]
+  uint32_t mask;
+  RT_DEV uint32_t key(float tn, int ref) const { return (__float_as_uint(tn) & ~mask) | (uint32_t)ref; }
+  RT_DEV float key_tn(uint32_t k) const { return __uint_as_float(k & ~mask); }
+  RT_DEV int key_ref(uint32_t k) const { return (int)(k & mask); }
 };
 
 // Leaves whose box a node step found worth testing wait here until the wave
@@ -456,9 +517,13 @@ struct tree_search {
     consider_sphere<COUNTED>(sv.leaf_sph[pos], sv.leaf_idx[pos], o, d, a, c, k);
   }
 
-  RT_DEV void step_node(const scene_view& sv, trav_stack<PACKED> stk, lane_counters& k) {
-    const unsigned char* nd = reinterpret_cast<const unsigned char*>(sv.nodes) + (size_t)cur * (PACKED ? RT_LDS_NODE_STRIDE : sizeof(bvh4_node));
-    const int4 ref = reinterpret_cast<const int4*>(nd)[6];
+  // `staged`: where stage_nodes() put this lane's node (trees read from HBM; unused when the
+  // whole tree is in LDS).
+  RT_DEV void step_node(const scene_view& sv, trav_stack<PACKED> stk, uint32_t staged, lane_counters& k) {
+    const unsigned char* nd = rt_lds + staged;
+    if (PACKED) nd = reinterpret_cast<const unsigned char*>(sv.nodes) + (size_t)cur * RT_LDS_NODE_STRIDE;
+    const int4 ref = PACKED ? reinterpret_cast<const int4*>(nd)[6]
+                            : *reinterpret_cast<const int4*>(reinterpret_cast<const unsigned char*>(sv.nodes) + (size_t)cur * sizeof(bvh4_node) + 96);
     const int refs[4] = {ref.x, ref.y, ref.z, ref.w};
     float tn[4], tf[4];
     if (SELECT) {
@@ -474,14 +539,20 @@ struct tree_search {
       child_interval_selected(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, sl, c.best_t, tn[2], tf[2]);
       child_interval_selected(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, sl, c.best_t, tn[3], tf[3]);
     } else {
-      const float4 lox = reinterpret_cast<const float4*>(nd)[0];
-      const float4 loy = reinterpret_cast<const float4*>(nd)[1];
-      const float4 loz = reinterpret_cast<const float4*>(nd)[2];
-      const float4 hix = reinterpret_cast<const float4*>(nd)[3];
-      const float4 hiy = reinterpret_cast<const float4*>(nd)[4];
-      const float4 hiz = reinterpret_cast<const float4*>(nd)[5];
+      // trees read from HBM: the first pieces of the node come from the staging area, the others
+      // from the node itself (both address calculations fold away for trees in LDS)
+      const unsigned char* rest = PACKED ? nd : reinterpret_cast<const unsigned char*>(sv.nodes) + (size_t)cur * sizeof(bvh4_node);
+#define RT_PIECE(i) (*reinterpret_cast<const float4*>((!PACKED && (i) < RT_STAGE_PIECES ? nd : rest) + 16 * (i)))
+      const float4 hiy = RT_PIECE(4);
+      const float4 hiz = RT_PIECE(5);
       float4 rmin = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (!PAD_RAY) rmin = reinterpret_cast<const float4*>(nd)[7];
+      if (!PAD_RAY) rmin = RT_PIECE(7);
+      if (!PACKED) stage_wait();
+      const float4 lox = RT_PIECE(0);
+      const float4 loy = RT_PIECE(1);
+      const float4 loz = RT_PIECE(2);
+      const float4 hix = RT_PIECE(3);
+#undef RT_PIECE
       child_interval<PAD_RAY>(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, rmin.x, o, sl, c.best_t, tn[0], tf[0]);
       child_interval<PAD_RAY>(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, rmin.y, o, sl, c.best_t, tn[1], tf[1]);
       child_interval<PAD_RAY>(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, rmin.z, o, sl, c.best_t, tn[2], tf[2]);
@@ -510,90 +581,56 @@ struct tree_search {
       const int pos = ~r;
       consider_sphere<COUNTED>(sv.leaf_sph[pos], sv.leaf_idx[pos], o, d, a, c, k);
     }
-    if (PACKED) {
-      uint32_t key[4];
+    uint32_t key[4];
 #pragma unroll
-      for (int ch = 0; ch < 4; ch++) {
-        const bool go = ok[ch] && refs[ch] >= 0 && tn[ch] <= c.best_t;
-        key[ch] = go ? trav_stack<true>::key(tn[ch], refs[ch]) : 0xFFFFFFFFu;
-      }
-      // sort the four keys ascending (invalid = all ones sinks to the end)
+    for (int ch = 0; ch < 4; ch++) {
+      const bool go = ok[ch] && refs[ch] >= 0 && tn[ch] <= c.best_t;
+      key[ch] = go ? stk.key(tn[ch], refs[ch]) : 0xFFFFFFFFu;
+    }
+    // sort the four keys ascending (invalid = all ones sinks to the end)
 #define RT_CE(i, j)                               \
   do {                                            \
     const uint32_t lo_ = min(key[i], key[j]);     \
     key[j] = max(key[i], key[j]);                 \
     key[i] = lo_;                                 \
   } while (0)
-      RT_CE(0, 1); RT_CE(2, 3); RT_CE(0, 2); RT_CE(1, 3); RT_CE(1, 2);
+    RT_CE(0, 1); RT_CE(2, 3); RT_CE(0, 2); RT_CE(1, 3); RT_CE(1, 2);
 #undef RT_CE
-      // The nearest child is next; the others go on the stack, farthest first, so
-      // that the nearest of them is popped first.  Three unconditional stores:
-      // key[e] of cnt valid keys belongs at sp + cnt-1-e; the keys that are not
-      // valid, and those that do not fit, go to row STACK, which nobody reads.
-      const int cnt = (key[0] != 0xFFFFFFFFu ? 1 : 0) + (key[1] != 0xFFFFFFFFu ? 1 : 0) + (key[2] != 0xFFFFFFFFu ? 1 : 0) +
-                      (key[3] != 0xFFFFFFFFu ? 1 : 0);
+    // The nearest child is next; the others go on the stack, farthest first, so
+    // that the nearest of them is popped first.  Three unconditional stores:
+    // key[e] of cnt valid keys belongs at sp + cnt-1-e; the keys that are not
+    // valid, and those that do not fit into the LDS rows, go to row STACK, which
+    // nobody reads.  Trees read from HBM keep the entries beyond the LDS rows in
+    // their overflow buffer; for trees in LDS an overflow sends the ray to the scan.
+    const int cnt = (key[0] != 0xFFFFFFFFu ? 1 : 0) + (key[1] != 0xFFFFFFFFu ? 1 : 0) + (key[2] != 0xFFFFFFFFu ? 1 : 0) +
+                    (key[3] != 0xFFFFFFFFu ? 1 : 0);
 #pragma unroll
-      for (int e = 1; e <= 3; e++) {
-        const int row = e < cnt ? min(sp + cnt - 1 - e, STACK) : STACK;
-        stk.col[row * 64] = key[e];
+    for (int e = 1; e <= 3; e++) {
+      const int want = sp + cnt - 1 - e;
+      const int row = e < cnt ? min(want, STACK) : STACK;
+      stk.col[row * 64] = key[e];
+      if (!PACKED && e < cnt && want >= STACK) {
+        if (want - STACK < sv.ovf_cap) sv.ovf_col[(size_t)(want - STACK) * 64] = key[e];
+        else c.redo = true;
       }
-      const int grown = sp + max(cnt - 1, 0);
-      c.redo = c.redo || grown > STACK;
-      sp = min(grown, STACK);
-      if (key[0] != 0xFFFFFFFFu) {
-        cur = trav_stack<true>::key_ref(key[0]);
+    }
+    const int grown = sp + max(cnt - 1, 0), room = PACKED ? STACK : STACK + sv.ovf_cap;
+    c.redo = c.redo || grown > room;
+    sp = min(grown, room);
+    if (key[0] != 0xFFFFFFFFu) {
+      cur = stk.key_ref(key[0]);
+      return;
+    }
+    cur = -1;
+    while (sp > 0) {
+      sp--;
+      // The LDS row is read unconditionally (row clamped) and replaced by the overflow row where
+      // the entry lives there: a pointer chosen between the two memories would need flat loads.
+      uint32_t e = stk.col[min(sp, STACK - 1) * 64];
+      if (!PACKED && sp >= STACK) e = sv.ovf_col[(size_t)(sp - STACK) * 64];
+      if (stk.key_tn(e) <= c.best_t) {
+        cur = stk.key_ref(e);
         return;
-      }
-      cur = -1;
-      while (sp > 0) {
-        sp--;
-        const uint32_t e = stk.col[sp * 64];
-        if (trav_stack<true>::key_tn(e) <= c.best_t) {
-          cur = trav_stack<true>::key_ref(e);
-          return;
-        }
-      }
-    } else {
-      // nearest child continues, the others are pushed with their entry parameter
-      int near = -1;
-      float near_tn = __builtin_inff();
-      bool go[4];
-#pragma unroll
-      for (int ch = 0; ch < 4; ch++) {
-        go[ch] = ok[ch] && refs[ch] >= 0 && tn[ch] <= c.best_t;
-        if (go[ch] && (near < 0 || tn[ch] < near_tn)) {
-          near = ch;
-          near_tn = tn[ch];
-        }
-      }
-#pragma unroll
-      for (int ch = 0; ch < 4; ch++) {
-        if (go[ch] && ch != near) {
-          if (sp < STACK) {
-            stk.col[sp * 128] = (uint32_t)refs[ch];
-            stk.col[sp * 128 + 64] = __float_as_uint(tn[ch]);
-            sp++;
-          } else if (sp - STACK < sv.ovf_cap) {
-            sv.ovf_col[(size_t)(sp - STACK) * 128] = (uint32_t)refs[ch];
-            sv.ovf_col[(size_t)(sp - STACK) * 128 + 64] = __float_as_uint(tn[ch]);
-            sp++;
-          } else {
-            c.redo = true;
-          }
-        }
-      }
-      if (near >= 0) {
-        cur = near == 0 ? refs[0] : near == 1 ? refs[1] : near == 2 ? refs[2] : refs[3];
-        return;
-      }
-      cur = -1;
-      while (sp > 0) {
-        sp--;
-        const uint32_t* e = sp < STACK ? stk.col + sp * 128 : sv.ovf_col + (size_t)(sp - STACK) * 128;
-        if (__uint_as_float(e[64]) <= c.best_t) {
-          cur = (int)e[0];
-          return;
-        }
       }
     }
   }
