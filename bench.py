@@ -246,6 +246,8 @@ def main():
                                   "unit": "TFLOP/s", "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
                                   "kernel": kname, "kernel_ms": avg_kernel_ms,
                                   "algorithmic_gflop_per_launch": flops / 1e9}
+        if traffic:  # fabric bytes (Infinity Cache + HBM reads behind L2, and writes) per second of kernel time
+            result["roofline"]["traffic_gbs"] = traffic / (avg_kernel_ms * 1e-3) / 1e9
         result["counters_per_launch"] = counters
         if not args.no_cpu_baseline and world == 1:
             threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
