@@ -352,7 +352,16 @@ int split_fineness() {
 
 // Samples per pixel of the cost-probe pass, and the switch for two-pass
 // rendering (RT_TWO_PASS=0 in the environment turns it off, for comparison).
-constexpr int kProbeSamples = 16;
+constexpr int kProbeSamplesDefault = 16;
+// RT_PROBE_SAMPLES overrides, for tuning (the split of a frame into probe and main pass never changes the image).
+int probe_samples() {
+  static int v = [] {
+    const char* e = getenv("RT_PROBE_SAMPLES");
+    int x = e ? atoi(e) : kProbeSamplesDefault;
+    return x < 1 ? 1 : (x > 256 ? 256 : x);
+  }();
+  return v;
+}
 bool two_pass_enabled() {
   static bool v = [] {
     const char* e = getenv("RT_TWO_PASS");
@@ -536,7 +545,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   // that order: the tail then consists of the cheapest pixels.
   const size_t n_rect = (size_t)tw * (size_t)th;
   const int n_samples = p->sample_end - p->sample_begin;
-  const bool two_pass = two_pass_enabled() && n_samples >= 4 * kProbeSamples && n_rect >= 16384;
+  const bool two_pass = two_pass_enabled() && n_samples >= 4 * probe_samples() && n_rect >= 16384;
   HIP_TRY(hipEventRecord(c->ev_k0, c->stream));
   hipError_t e;
   if (!two_pass) {
@@ -554,7 +563,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
     HIP_TRY(c->sort_temp.resize(temp_bytes > 0 ? temp_bytes : 1));
     render_args probe = a;
     probe.pass = 1;
-    probe.p.sample_end = p->sample_begin + kProbeSamples;
+    probe.p.sample_end = p->sample_begin + probe_samples();
     probe.carry_colour = c->carry_colour.p;
     probe.carry_rng = c->carry_rng.p;
     probe.carry_key = c->carry_key.p;
@@ -567,7 +576,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       // Plan the main pass: one job per pixel, except that the most expensive pixels are cut into
       // several sample ranges (counter RNG only: the reference's generator runs through a pixel's
       // samples and cannot start in the middle).
-      const int main_begin = p->sample_begin + kProbeSamples, main_samples = p->sample_end - main_begin;
+      const int main_begin = p->sample_begin + probe_samples(), main_samples = p->sample_end - main_begin;
       const uint32_t n = (uint32_t)n_rect;
       // a job should be a small fraction (1 / split_fineness()) of a lane's fair share of the frame
       const uint32_t lanes = (uint32_t)c->n_cu * 1024u * (uint32_t)split_fineness();

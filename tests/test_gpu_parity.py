@@ -244,3 +244,39 @@ def test_two_pass_render_matches_oracle(renderer, accel, rng_mode):
     assert_same_f32(lin, oracle.resolve(acc, 64)[0], "linear radiance")
     for k in ("paths", "segments", "hits", "sky", "lambertian", "metallic", "dialectric", "unit_tries", "disk_tries"):
         assert c[k] == oc[k], k
+
+
+def _scaled_cloud(n, seed, scale):
+    """The sphere cloud with its centres pulled towards the origin (radii kept): dense enough that paths bounce."""
+    scene = rt.build_scene(rt.SCENE_CLOUD, n=n, seed=seed)
+    rec = np.frombuffer(scene.spheres, dtype=np.uint8).reshape(-1, 32).copy()
+    centres = rec[:, 16:28].copy().view(np.float32) * np.float32(scale)
+    rec[:, 16:28] = centres.view(np.uint8)
+    return rt.Scene(rec.tobytes(), scene.materials)
+
+
+@pytest.mark.parametrize("scale,lookfrom_z", [(0.05, 60.0), (1.0, 300.0)])
+def test_render_with_a_tree_too_big_for_lds(renderer, scale, lookfrom_z):
+    """20 000 spheres: the hierarchy is read from HBM (staged node fetch, overflowing traversal stack) by the
+    render kernel.  Packed tightly the per-ray box pad applies, spread out the per-box one; both must
+    reproduce the scan bit for bit, on the GPU and in the CPU restatement."""
+    scene = _scaled_cloud(20000, 0xC10D, scale)
+    cam = rt.scene_camera(rt.SCENE_CLOUD)
+    cam.lookfrom[2] = lookfrom_z
+    p = rt.make_params(cam, 96, 54, 4, rng_mode=rt.RNG_COUNTER)
+    frames = {}
+    for accel in (rt.ACCEL_LBVH, rt.ACCEL_LINEAR):
+        renderer.upload(scene, accel)
+        renderer.clear()
+        renderer.render(p, counted=True)
+        frames[accel] = renderer.readback(rgb8=False)[0]
+        if accel == rt.ACCEL_LBVH:
+            c = renderer.counters()
+            assert c["node_tests"] > 0 and renderer.lbvh_depth() > 8
+            want = "rt_render_kernel<lbvh4,hbm,pad_ray>" if scale < 1.0 else "rt_render_kernel<lbvh4,hbm,pad_node>"
+            assert renderer.last_kernel_ms()[1] == want
+            assert c["hits"] > (1000 if scale < 1.0 else 20)
+    assert_same_f32(frames[rt.ACCEL_LBVH], frames[rt.ACCEL_LINEAR], "tree vs scan")
+    acc, oc = oracle.render(scene, p, threads=16)
+    assert_same_f32(frames[rt.ACCEL_LBVH], oracle.resolve(acc, 4)[0], "tree vs CPU restatement")
+    assert c["hits"] == oc["hits"] and c["segments"] == oc["segments"]
