@@ -84,9 +84,18 @@ def cpu_baseline_render(rt, scene, cam, cfg, threads):
     t0 = time.perf_counter()
     _, c = oracle.render(scene, p, threads=threads)
     dt = time.perf_counter() - t0
-    return {"value": c["paths"] / dt / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
-            "sample": f"same scene and camera, {w}x{h} at {spp} spp ({c['paths']} paths, {dt:.1f} s wall), "
-                      f"CPU restatement of the reference shader (linear scan), {threads} threads"}
+    out = {"value": c["paths"] / dt / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
+           "sample": f"same scene and camera, {w}x{h} at {spp} spp ({c['paths']} paths, {dt:.1f} s wall), "
+                     f"CPU restatement of the reference shader (linear scan), {threads} threads"}
+    # one thread, on a band of rows sized for about 5 s
+    one = rt.make_params(cam, w, h, 1, rng_mode=probe.rng_mode)
+    one.tile_y1 = int(max(1, min(h, round(h * (rate / max(threads, 1)) * 5.0 / (w * h)))))
+    t0 = time.perf_counter()
+    _, c1 = oracle.render(scene, one, threads=1)
+    dt1 = time.perf_counter() - t0
+    out["single_thread"] = {"value": c1["paths"] / dt1 / 1e6, "unit": "Mpaths/s",
+                            "sample": f"rows 0..{one.tile_y1 - 1} at 1 spp ({c1['paths']} paths, {dt1:.1f} s wall)"}
+    return out
 
 
 def cpu_baseline_trace(rt, scene, threads, seed):
