@@ -79,6 +79,22 @@ constexpr int kMaxBig = 8;
 
 }  // namespace
 
+// Work arrays of the hierarchy build.  They stay with the context between uploads (a scene that is
+// rebuilt every frame should not pay fifteen allocations per build) unless they are large.
+struct lbvh_scratch {
+  dev_buf<uint32_t> bounds, codes, codes_sorted, index, index_sorted;
+  dev_buf<int> child0, child1, node_parent, leaf_parent, scalars, slot_of;
+  dev_buf<unsigned int> arrivals;
+  dev_buf<float> node_box, node_rmin;
+  dev_buf<unsigned char> temp;
+  void release() {
+    bounds.release(); codes.release(); codes_sorted.release(); index.release(); index_sorted.release();
+    child0.release(); child1.release(); node_parent.release(); leaf_parent.release(); scalars.release();
+    slot_of.release(); arrivals.release(); node_box.release(); node_rmin.release(); temp.release();
+  }
+};
+constexpr size_t kKeepScratchSpheres = (size_t)1 << 18;  // builds up to this size keep their work arrays
+
 struct rt_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -116,6 +132,7 @@ struct rt_ctx {
 
   dev_buf<uint32_t> seed_tex;
   dev_buf<unsigned long long> queue;  // work-queue head of the running launch
+  lbvh_scratch build;
   dev_buf<uint32_t> ovf;              // traversal-stack overflow of the running launch (HBM-resident trees)
   // two-pass rendering: per-pixel carry of the probe pass and the sorted pixel order
   dev_buf<float> carry_colour;
@@ -180,15 +197,15 @@ int build_lbvh(rt_ctx* c) {
   HIP_TRY(c->leaf_idx.resize((size_t)n));
   HIP_TRY(c->nodes.resize((size_t)(n > 1 ? n - 1 : 1)));
 
-  dev_buf<uint32_t> bounds, codes, codes_sorted, index, index_sorted;
-  dev_buf<int> child0, child1, node_parent, leaf_parent, scalars, slot_of;
-  dev_buf<unsigned int> arrivals;
-  dev_buf<float> node_box, node_rmin;
-  dev_buf<unsigned char> temp;
+  lbvh_scratch& w = c->build;
+  dev_buf<uint32_t>&bounds = w.bounds, &codes = w.codes, &codes_sorted = w.codes_sorted, &index = w.index, &index_sorted = w.index_sorted;
+  dev_buf<int>&child0 = w.child0, &child1 = w.child1, &node_parent = w.node_parent, &leaf_parent = w.leaf_parent,
+              &scalars = w.scalars, &slot_of = w.slot_of;
+  dev_buf<unsigned int>& arrivals = w.arrivals;
+  dev_buf<float>&node_box = w.node_box, &node_rmin = w.node_rmin;
+  dev_buf<unsigned char>& temp = w.temp;
   auto cleanup = [&]() {
-    bounds.release(); codes.release(); codes_sorted.release(); index.release(); index_sorted.release();
-    child0.release(); child1.release(); node_parent.release(); leaf_parent.release(); scalars.release();
-    slot_of.release(); arrivals.release(); node_box.release(); node_rmin.release(); temp.release();
+    if ((size_t)n > kKeepScratchSpheres) w.release();
   };
 #define BUILD_TRY(expr)                                                                       \
   do {                                                                                        \
@@ -675,7 +692,7 @@ void rt_destroy(rt_ctx* c) {
   c->sph.release(); c->inv_r.release(); c->sph_mat.release(); c->mat_type.release(); c->mat_a.release();
   c->big_sph.release(); c->big_idx.release(); c->tree_sph.release(); c->tree_r.release(); c->tree_orig.release();
   c->nodes.release(); c->leaf_sph.release(); c->leaf_r.release(); c->leaf_idx.release();
-  c->accum_own.release(); c->seed_tex.release(); c->queue.release(); c->counters.release(); c->ovf.release();
+  c->accum_own.release(); c->seed_tex.release(); c->queue.release(); c->counters.release(); c->ovf.release(); c->build.release();
   c->carry_colour.release(); c->carry_rng.release(); c->carry_key.release(); c->carry_idx.release();
   c->plan_parts.release(); c->plan_first.release(); c->plan_counts.release(); c->plan_total.release();
   c->plan_jobs.release(); c->split_samples.release(); c->scan_temp.release();
