@@ -221,7 +221,7 @@ struct searcher {
 // traversal steps for the others.
 #define RT_PHASE_VOTE 52
 #define RT_TRACE_VOTE 16
-#define RT_LEAF_VOTE 16
+#define RT_LEAF_VOTE 8
 
 // Work items (pixels, rays) come from one global counter.  Same-address atomics
 // from the whole chip complete at roughly 80 million per second, so a wave takes
