@@ -8,13 +8,16 @@ A step is one pass of the hot path over one batch of synthetic input:
   c1            the reference's own default render (320x180, 8 spp, xorshift RNG)   -> Mpaths/s
   c3            the Perlin-textured scene, 1920x1080 at 1024 spp                   -> Mpaths/s
   c4            2^20 spheres, a 10^8-ray closest-hit batch (LBVH)                  -> Mrays/s
+  c5            the 487-sphere scene at 3840x2160, 4096 spp in total                -> Mpaths/s
 Scene and rays are resident in HBM before the timed region starts.
 
 With N > 1 (one process per GPU, started by torch.distributed.run) every rank
 renders its own 256-sample range of the same frame into its own accumulator
 (weak scaling: N x 256 spp in total) and the accumulators are summed onto rank
 0 with an RCCL reduce inside the timed step.  c4 splits the ray batch by index
-range and needs no collective.
+range and needs no collective.  c5 is the fixed-size job (strong scaling): the 4096 samples per pixel
+are divided among the ranks, by row band and sample range (two bands from four ranks on), and
+summed the same way.
 
 Prints ONE JSON line on rank 0.
 """
@@ -34,6 +37,8 @@ CONFIGS = {
     "c1": dict(scene="default", width=320, height=180, spp=8, rng="xorshift", workload="default scene 320x180x8spp depth50 (reference's built-in render)"),
     "c2": dict(scene="random_spheres", width=1920, height=1080, spp=256, rng="counter", workload="487-sphere scene 1920x1080x256spp depth50"),
     "c3": dict(scene="perlin", width=1920, height=1080, spp=1024, rng="counter", workload="Perlin-textured scene 1920x1080x1024spp depth50"),
+    "c5": dict(scene="random_spheres", width=3840, height=2160, spp=4096, rng="counter", strong=True,
+               workload="487-sphere scene 3840x2160x4096spp depth50"),
     "c4": dict(scene="cloud", n_spheres=1 << 20, n_rays=100_000_000, workload="2^20 spheres, 1e8-ray closest-hit batch"),
 }
 
@@ -56,7 +61,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))  # c5 at N=1 takes about 6 s per step
     ap.add_argument("--accel", default="lbvh", choices=["lbvh", "linear"])
     ap.add_argument("--width", type=int)
     ap.add_argument("--height", type=int)
@@ -190,8 +195,11 @@ def main():
         accum = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
         r.set_accumulator(accum.data_ptr(), w, h)
         from raytrace_amd import distributed as rtd
-        share = rtd.split_frame(h, spp * world, world)[rank]  # rank r: samples [r*spp, (r+1)*spp) of every pixel
-        p = rtd.apply_share(rt.make_params(cam, w, h, spp * world, rng_mode=rng_mode), share)
+        strong = bool(cfg.get("strong"))
+        total_spp = spp if strong else spp * world
+        # weak: rank r renders samples [r*spp, (r+1)*spp) of every pixel; strong: a row band x sample range of the fixed job
+        share = rtd.split_frame(h, total_spp, world, row_groups=2 if strong and world >= 4 and world % 2 == 0 else 1)[rank]
+        p = rtd.apply_share(rt.make_params(cam, w, h, total_spp, rng_mode=rng_mode), share)
 
         def step(counted=False):
             r.clear()  # memset + render are ordered on the library's own stream
@@ -203,13 +211,15 @@ def main():
 
         step(counted=True)
         counters = r.counters()
-        units_per_step = w * h * spp * world
+        units_per_step = w * h * total_spp
         unit, metric = "Mpaths/s", "path-tracing throughput at %dx%d (Mpaths/s)" % (w, h)
         algo_bytes = None
         result["config"] = {"workload": f"{cfg['workload'].split(' ')[0]} scene {w}x{h}x{spp}spp depth50" if (args.width or args.height or args.spp) else cfg["workload"],
                             "accel": args.accel, "spheres": scene.n_spheres, "rng": cfg["rng"],
-                            "lbvh_depth": r.lbvh_depth(), "global_samples_per_pixel": spp * world,
-                            "parallelism": f"sample ranges x{world} + RCCL reduce" if world > 1 else "single GPU"}
+                            "lbvh_depth": r.lbvh_depth(), "global_samples_per_pixel": total_spp,
+                            "parallelism": (f"row bands x sample ranges over {world} ranks + RCCL reduce" if strong else
+                                            f"sample ranges x{world} + RCCL reduce") if world > 1 else "single GPU"}
+        result["_scaling"] = "strong" if strong else "weak"
         if accel == rt.ACCEL_LBVH:
             result["lbvh_build_ms"] = r.last_build_ms()
 
@@ -242,7 +252,7 @@ def main():
         result.update({
             "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": result.pop("_scaling", "weak"), "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         })
         traffic = measured_traffic(kname, result["config"]["workload"])
         if args.config == "c4":

@@ -68,6 +68,8 @@ struct dev_buf {
 
 // Memory for the per-sample radiance of pixels whose main pass is cut into several jobs.
 constexpr size_t kSplitBudgetBytes = (size_t)1 << 30;
+// The same for the probe pass in sweeps (every pixel's probe samples): beyond this the probe runs unsplit.
+constexpr size_t kProbeBudgetBytes = (size_t)4 << 30;
 // Largest dynamic LDS a launch may ask for (the CU has 160 KiB).
 constexpr size_t kMaxLdsBytes = 160 * 1024;
 // The linear scan stages its sphere records in LDS up to this many bytes.
@@ -142,7 +144,7 @@ struct rt_ctx {
   dev_buf<uint32_t> plan_parts, plan_first, plan_counts;
   dev_buf<unsigned long long> plan_total;
   dev_buf<uint4> plan_jobs;
-  dev_buf<float> split_samples;
+  dev_buf<float> split_samples, probe_samples;
   dev_buf<unsigned char> scan_temp;
   int n_cu = 0;
   dev_buf<unsigned long long> counters;
@@ -356,6 +358,16 @@ int leaf_vote() {
   return v;
 }
 
+// Sweeps of the probe pass (RT_PROBE_SWEEPS overrides, 1 = unsplit probe).
+int probe_sweeps() {
+  static int v = [] {
+    const char* e = getenv("RT_PROBE_SWEEPS");
+    int x = e ? atoi(e) : 16;
+    return x < 1 ? 1 : (x > 64 ? 64 : x);
+  }();
+  return v;
+}
+
 // How finely the main pass of two-pass rendering cuts expensive pixels: no job should exceed
 // 1/fineness of what a lane does on average (RT_SPLIT_FINENESS overrides, for tuning).
 int split_fineness() {
@@ -369,15 +381,22 @@ int split_fineness() {
 
 // Samples per pixel of the cost-probe pass, and the switch for two-pass
 // rendering (RT_TWO_PASS=0 in the environment turns it off, for comparison).
-constexpr int kProbeSamplesDefault = 16;
-// RT_PROBE_SAMPLES overrides, for tuning (the split of a frame into probe and main pass never changes the image).
-int probe_samples() {
-  static int v = [] {
+// The probe takes an eighth of the samples, between 8 and a cap: 32 when it runs in sweeps (counter RNG: short jobs
+// in tile order are about as efficient as the sorted main pass, and a longer probe measures costs better), 16 when
+// every pixel's probe is one job.  RT_PROBE_SAMPLES overrides the cap, for tuning (the split of a frame into probe
+// and main pass never changes the image).  Two-pass rendering needs at least 64 samples.
+constexpr int kMinTwoPassSamples = 64;
+int probe_samples(int n_samples, bool swept) {
+  static int cap = [] {
     const char* e = getenv("RT_PROBE_SAMPLES");
-    int x = e ? atoi(e) : kProbeSamplesDefault;
-    return x < 1 ? 1 : (x > 256 ? 256 : x);
+    int x = e ? atoi(e) : 0;
+    return x < 0 ? 0 : (x > 256 ? 256 : x);
   }();
-  return v;
+  const int most = cap > 0 ? cap : (swept ? 32 : 16);
+  int n = n_samples / 8;
+  n = n < 8 ? 8 : n;
+  n = n > most ? most : n;
+  return n < n_samples ? n : n_samples;
 }
 bool two_pass_enabled() {
   static bool v = [] {
@@ -549,6 +568,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
     }
   };
   a.pass = 0;
+  a.sweeps = 1;
   a.jobs = nullptr;
   a.n_jobs = nullptr;
   a.split_samples = nullptr;
@@ -562,7 +582,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   // that order: the tail then consists of the cheapest pixels.
   const size_t n_rect = (size_t)tw * (size_t)th;
   const int n_samples = p->sample_end - p->sample_begin;
-  const bool two_pass = two_pass_enabled() && n_samples >= 4 * probe_samples() && n_rect >= 16384;
+  const bool two_pass = two_pass_enabled() && n_samples >= kMinTwoPassSamples && n_rect >= 16384;
   HIP_TRY(hipEventRecord(c->ev_k0, c->stream));
   hipError_t e;
   if (!two_pass) {
@@ -580,12 +600,36 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
     HIP_TRY(c->sort_temp.resize(temp_bytes > 0 ? temp_bytes : 1));
     render_args probe = a;
     probe.pass = 1;
-    probe.p.sample_end = p->sample_begin + probe_samples();
     probe.carry_colour = c->carry_colour.p;
     probe.carry_rng = c->carry_rng.p;
     probe.carry_key = c->carry_key.p;
     probe.carry_idx = c->carry_idx.p;
+    // Counter RNG: the probe runs in sweeps (see render_args), its samples in a buffer of their own.
+    bool swept = p->rng_mode == RT_RNG_COUNTER && probe_sweeps() > 1;
+    int n_probe = probe_samples(n_samples, swept);
+    if (swept && n_rect * (size_t)n_probe * 3 * sizeof(float) > kProbeBudgetBytes) {
+      swept = false;
+      n_probe = probe_samples(n_samples, false);
+    }
+    const int sweeps = probe_sweeps() < n_probe ? probe_sweeps() : n_probe;
+    probe.p.sample_end = p->sample_begin + n_probe;
+    if (swept) {
+      HIP_TRY(c->probe_samples.resize(n_rect * (size_t)n_probe * 3));
+      HIP_TRY(hipMemsetAsync(c->carry_key.p, 0, n_rect * sizeof(uint32_t), c->stream));
+      probe.pass = 3;
+      probe.sweeps = sweeps;
+      probe.split_samples = c->probe_samples.p;
+      probe.main_samples = n_probe;
+    }
     e = launch(probe, p);
+    if (e == hipSuccess && swept) {
+      rt_probe_sum_kernel<<<(unsigned)((n_rect + 255) / 256), 256, 0, c->stream>>>(
+          (uint32_t)n_rect, c->probe_samples.p, n_probe, p->tile_x0, p->tile_y0, tw, p->width, c->accum(), c->carry_colour.p,
+          c->carry_rng.p, c->carry_key.p, c->carry_idx.p);
+      e = hipGetLastError();
+      probe.pass = 1;  // what follows copies `probe` for the main pass
+      probe.sweeps = 1;
+    }
     if (e == hipSuccess)
       e = rocprim::radix_sort_pairs(c->sort_temp.p, temp_bytes, c->carry_key.p, c->order_key.p, c->carry_idx.p,
                                     c->order_idx.p, n_rect, 0, 12, c->stream);
@@ -593,7 +637,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       // Plan the main pass: one job per pixel, except that the most expensive pixels are cut into
       // several sample ranges (counter RNG only: the reference's generator runs through a pixel's
       // samples and cannot start in the middle).
-      const int main_begin = p->sample_begin + probe_samples(), main_samples = p->sample_end - main_begin;
+      const int main_begin = p->sample_begin + n_probe, main_samples = p->sample_end - main_begin;
       const uint32_t n = (uint32_t)n_rect;
       // a job should be a small fraction (1 / split_fineness()) of a lane's fair share of the frame
       const uint32_t lanes = (uint32_t)c->n_cu * 1024u * (uint32_t)split_fineness();
@@ -695,7 +739,7 @@ void rt_destroy(rt_ctx* c) {
   c->accum_own.release(); c->seed_tex.release(); c->queue.release(); c->counters.release(); c->ovf.release(); c->build.release();
   c->carry_colour.release(); c->carry_rng.release(); c->carry_key.release(); c->carry_idx.release();
   c->plan_parts.release(); c->plan_first.release(); c->plan_counts.release(); c->plan_total.release();
-  c->plan_jobs.release(); c->split_samples.release(); c->scan_temp.release();
+  c->plan_jobs.release(); c->split_samples.release(); c->probe_samples.release(); c->scan_temp.release();
   c->order_key.release(); c->order_idx.release(); c->sort_temp.release(); c->out_linear.release(); c->out_rgb8.release();
   if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
   if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);

@@ -86,7 +86,13 @@ struct render_args {
   //           running sum, RNG state and segment count in the carry arrays, not in accum
   //   pass 2  main: the remaining samples, taken job by job (most expensive pixels first),
   //           each pixel continuing from its carried sum and RNG state
+  //   pass 3  probe in `sweeps` sweeps over the image (counter RNG only): every pixel's probe samples
+  //           are cut into that many ranges taken by different lanes, so that the pixels that turn
+  //           out expensive hold the end of the launch up for a fraction of their cost only; every
+  //           sample's radiance goes to split_samples (row = rect pixel), the segment counts are
+  //           added up in carry_key, and rt_probe_sum_kernel forms what pass 1 would have left
   int pass;
+  int sweeps;
   float* carry_colour;         // 3 floats per rect pixel
   uint32_t* carry_rng;
   uint32_t* carry_key;         // pass 1 writes the sort key (small = expensive) ...
@@ -296,7 +302,8 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
 
   const int tw = P.tile_x1 - P.tile_x0, th = P.tile_y1 - P.tile_y0;
   const int tiles_x = (tw + 7) >> 3, tiles_y = (th + 7) >> 3;
-  const uint32_t total_items = A.pass == 2 ? *A.n_jobs : (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
+  const uint32_t tile_items = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
+  const uint32_t total_items = A.pass == 2 ? *A.n_jobs : (A.pass == 3 ? tile_items * (uint32_t)A.sweeps : tile_items);
 
   lane_counters k = {};
   const f3 delta_u = mk3(P.delta_u[0], P.delta_u[1], P.delta_u[2]);
@@ -322,7 +329,9 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
   // The pixel's sample range is over: pass 0 / 2 add its sum to the image, the
   // probe pass parks it (with the RNG state and a cost key) for pass 2.
   auto close_pixel = [&]() {
-    if (A.pass == 1) {
+    if (A.pass == 3) {
+      atomicAdd(A.carry_key + rect_pixel, pixel_segments);
+    } else if (A.pass == 1) {
       float* dst = A.carry_colour + 3 * (size_t)rect_pixel;
       dst[0] = colour.x;
       dst[1] = colour.y;
@@ -444,7 +453,15 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
             x = P.tile_x0 + (int)(rect_pixel % (uint32_t)tw);
             y = P.tile_y0 + (int)(rect_pixel / (uint32_t)tw);
           } else {
-            const uint32_t tile = item >> 6, within = item & 63u;
+            uint32_t it = item;
+            if (A.pass == 3) {  // sweep q takes the q-th part of every pixel's probe samples
+              const uint32_t sweep = item / tile_items;
+              it = item - sweep * tile_items;
+              const int n_probe = P.sample_end - P.sample_begin;
+              job.y = (uint32_t)(P.sample_begin + (int)(((long long)n_probe * sweep) / A.sweeps));
+              job.z = (uint32_t)(P.sample_begin + (int)(((long long)n_probe * (sweep + 1)) / A.sweeps));
+            }
+            const uint32_t tile = it >> 6, within = it & 63u;
             x = P.tile_x0 + (int)(tile % (uint32_t)tiles_x) * 8 + (int)(within & 7u);
             y = P.tile_y0 + (int)(tile / (uint32_t)tiles_x) * 8 + (int)(within >> 3);
             rect_pixel = (uint32_t)(y - P.tile_y0) * (uint32_t)tw + (uint32_t)(x - P.tile_x0);
@@ -454,7 +471,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
             pixel = (uint32_t)y * (uint32_t)P.width + (uint32_t)x;
             s = (int)job.y;
             s_end = (int)job.z;
-            split_row = job.w;
+            split_row = A.pass == 3 ? rect_pixel : job.w;
             alive = false;
             pixel_segments = 0;
             if (A.pass == 2) {  // continue the sum and the RNG stream the probe pass left
@@ -464,8 +481,10 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
             } else {
               // the sum goes on from what earlier sample ranges left in the image (zero on a
               // fresh frame, fs:115): ranges rendered in order add up exactly as one render
-              const float* src = A.accum + 3 * (size_t)pixel;
-              colour = mk3(src[0], src[1], src[2]);
+              if (A.pass != 3) {  // (a probe in sweeps stores samples; rt_probe_sum_kernel adds them to the image's sum)
+                const float* src = A.accum + 3 * (size_t)pixel;
+                colour = mk3(src[0], src[1], src[2]);
+              }
               if (RNG == RT_RNG_XORSHIFT_REF) {
                 const uint32_t seed = A.seed_tex ? A.seed_tex[pixel] : 0u;  // fs:105-106
                 rng = seed ^ cantor_pair((uint32_t)x, (uint32_t)y);         // fs:107
@@ -589,6 +608,28 @@ __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order
   dst[0] = colour.x;
   dst[1] = colour.y;
   dst[2] = colour.z;
+}
+
+// After a probe in sweeps (pass 3): the pixel's probe samples are added in sample order onto what
+// earlier sample ranges left in the image, exactly as one lane would have added them; the summed
+// segment count becomes the sort key (small = expensive).
+__global__ __launch_bounds__(256) void rt_probe_sum_kernel(uint32_t n_rect, const float* probe_samples, int n_probe, int tile_x0,
+                                                          int tile_y0, int tile_w, int width, const float* accum,
+                                                          float* carry_colour, uint32_t* carry_rng, uint32_t* carry_key,
+                                                          uint32_t* carry_idx) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rect) return;
+  const int x = tile_x0 + (int)(i % (uint32_t)tile_w), y = tile_y0 + (int)(i / (uint32_t)tile_w);
+  const float* base = accum + 3 * ((size_t)y * (size_t)width + (size_t)x);
+  f3 colour = mk3(base[0], base[1], base[2]);
+  const float* src = probe_samples + (size_t)i * (size_t)n_probe * 3;
+  for (int s = 0; s < n_probe; s++) colour = colour + mk3(src[3 * s], src[3 * s + 1], src[3 * s + 2]);
+  carry_colour[3 * (size_t)i] = colour.x;
+  carry_colour[3 * (size_t)i + 1] = colour.y;
+  carry_colour[3 * (size_t)i + 2] = colour.z;
+  carry_rng[i] = 0u;  // the counter RNG re-keys every sample
+  carry_key[i] = 4095u - min(carry_key[i], 4095u);
+  carry_idx[i] = i;
 }
 
 struct trace_args {
