@@ -138,7 +138,7 @@ struct rt_ctx {
   dev_buf<uint32_t> ovf;              // traversal-stack overflow of the running launch (HBM-resident trees)
   // two-pass rendering: per-pixel carry of the probe pass and the sorted pixel order
   dev_buf<float> carry_colour;
-  dev_buf<uint32_t> carry_rng, carry_key, carry_idx, order_key, order_idx;
+  dev_buf<uint32_t> carry_rng, carry_cost, carry_key, carry_idx, order_key, order_idx;
   dev_buf<unsigned char> sort_temp;
   // main-pass jobs: parts per sorted pixel, their prefix sum, the job table, totals, per-sample store of split pixels
   dev_buf<uint32_t> plan_parts, plan_first, plan_counts;
@@ -358,6 +358,16 @@ int leaf_vote() {
   return v;
 }
 
+// Cost levels per power of two in the main pass's sort key, as a power of two (RT_COST_STEPS_LOG2 overrides, 0..6).
+int cost_steps_log2() {
+  static int v = [] {
+    const char* e = getenv("RT_COST_STEPS_LOG2");
+    int x = e ? atoi(e) : 3;
+    return x < 0 ? 0 : (x > 6 ? 6 : x);
+  }();
+  return v;
+}
+
 // Sweeps of the probe pass (RT_PROBE_SWEEPS overrides, 1 = unsplit probe).
 int probe_sweeps() {
   static int v = [] {
@@ -574,7 +584,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   a.split_samples = nullptr;
   a.main_samples = 0;
   a.carry_colour = nullptr;
-  a.carry_rng = a.carry_key = a.carry_idx = nullptr;
+  a.carry_rng = a.carry_cost = nullptr;
   // A pixel is the unit of work (its sum must be formed in sample order), so
   // the launch ends with the lanes that drew the most expensive pixels last.
   // With enough samples a short probe pass measures every pixel's cost, the
@@ -590,20 +600,20 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   } else {
     HIP_TRY(c->carry_colour.resize(3 * n_rect));
     HIP_TRY(c->carry_rng.resize(n_rect));
+    HIP_TRY(c->carry_cost.resize(n_rect));
     HIP_TRY(c->carry_key.resize(n_rect));
     HIP_TRY(c->carry_idx.resize(n_rect));
     HIP_TRY(c->order_key.resize(n_rect));
     HIP_TRY(c->order_idx.resize(n_rect));
     size_t temp_bytes = 0;
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, c->carry_key.p, c->order_key.p, c->carry_idx.p, c->order_idx.p,
-                                      n_rect, 0, 12, c->stream));
+                                      n_rect, 0, 31, c->stream));
     HIP_TRY(c->sort_temp.resize(temp_bytes > 0 ? temp_bytes : 1));
     render_args probe = a;
     probe.pass = 1;
     probe.carry_colour = c->carry_colour.p;
     probe.carry_rng = c->carry_rng.p;
-    probe.carry_key = c->carry_key.p;
-    probe.carry_idx = c->carry_idx.p;
+    probe.carry_cost = c->carry_cost.p;
     // Counter RNG: the probe runs in sweeps (see render_args), its samples in a buffer of their own.
     bool swept = p->rng_mode == RT_RNG_COUNTER && probe_sweeps() > 1;
     int n_probe = probe_samples(n_samples, swept);
@@ -615,7 +625,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
     probe.p.sample_end = p->sample_begin + n_probe;
     if (swept) {
       HIP_TRY(c->probe_samples.resize(n_rect * (size_t)n_probe * 3));
-      HIP_TRY(hipMemsetAsync(c->carry_key.p, 0, n_rect * sizeof(uint32_t), c->stream));
+      HIP_TRY(hipMemsetAsync(c->carry_cost.p, 0, n_rect * sizeof(uint32_t), c->stream));
       probe.pass = 3;
       probe.sweeps = sweeps;
       probe.split_samples = c->probe_samples.p;
@@ -625,14 +635,19 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
     if (e == hipSuccess && swept) {
       rt_probe_sum_kernel<<<(unsigned)((n_rect + 255) / 256), 256, 0, c->stream>>>(
           (uint32_t)n_rect, c->probe_samples.p, n_probe, p->tile_x0, p->tile_y0, tw, p->width, c->accum(), c->carry_colour.p,
-          c->carry_rng.p, c->carry_key.p, c->carry_idx.p);
+          c->carry_rng.p);
       e = hipGetLastError();
       probe.pass = 1;  // what follows copies `probe` for the main pass
       probe.sweeps = 1;
     }
+    if (e == hipSuccess) {
+      rt_sort_key_kernel<<<(unsigned)((n_rect + 255) / 256), 256, 0, c->stream>>>((uint32_t)n_rect, tw, cost_steps_log2(), /*8x8 tiles*/ 3, c->carry_cost.p, c->carry_key.p,
+                                                                                 c->carry_idx.p);
+      e = hipGetLastError();
+    }
     if (e == hipSuccess)
       e = rocprim::radix_sort_pairs(c->sort_temp.p, temp_bytes, c->carry_key.p, c->order_key.p, c->carry_idx.p,
-                                    c->order_idx.p, n_rect, 0, 12, c->stream);
+                                    c->order_idx.p, n_rect, 0, 31, c->stream);
     if (e == hipSuccess) {
       // Plan the main pass: one job per pixel, except that the most expensive pixels are cut into
       // several sample ranges (counter RNG only: the reference's generator runs through a pixel's
@@ -655,8 +670,8 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       HIP_TRY(c->scan_temp.resize(scan_bytes > 0 ? scan_bytes : 1));
       HIP_TRY(hipMemsetAsync(c->plan_total.p, 0, sizeof(unsigned long long), c->stream));
       const unsigned grid = (n + 255) / 256;
-      rt_plan_cost_kernel<<<grid < 1024 ? grid : 1024, 256, 0, c->stream>>>(c->order_key.p, n, c->plan_total.p);
-      rt_plan_count_kernel<<<grid, 256, 0, c->stream>>>(c->order_key.p, n, c->plan_total.p, lanes, max_split, main_samples,
+      rt_plan_cost_kernel<<<grid < 1024 ? grid : 1024, 256, 0, c->stream>>>(c->carry_cost.p, n, c->plan_total.p);
+      rt_plan_count_kernel<<<grid, 256, 0, c->stream>>>(c->carry_cost.p, c->order_idx.p, n, c->plan_total.p, lanes, max_split, main_samples,
                                                        splittable, c->plan_parts.p);
       HIP_TRY(hipGetLastError());
       HIP_TRY(rocprim::exclusive_scan(c->scan_temp.p, scan_bytes, c->plan_parts.p, c->plan_first.p, 0u, n, rocprim::plus<uint32_t>(),
@@ -737,7 +752,7 @@ void rt_destroy(rt_ctx* c) {
   c->big_sph.release(); c->big_idx.release(); c->tree_sph.release(); c->tree_r.release(); c->tree_orig.release();
   c->nodes.release(); c->leaf_sph.release(); c->leaf_r.release(); c->leaf_idx.release();
   c->accum_own.release(); c->seed_tex.release(); c->queue.release(); c->counters.release(); c->ovf.release(); c->build.release();
-  c->carry_colour.release(); c->carry_rng.release(); c->carry_key.release(); c->carry_idx.release();
+  c->carry_colour.release(); c->carry_rng.release(); c->carry_cost.release(); c->carry_key.release(); c->carry_idx.release();
   c->plan_parts.release(); c->plan_first.release(); c->plan_counts.release(); c->plan_total.release();
   c->plan_jobs.release(); c->split_samples.release(); c->probe_samples.release(); c->scan_temp.release();
   c->order_key.release(); c->order_idx.release(); c->sort_temp.release(); c->out_linear.release(); c->out_rgb8.release();

@@ -90,13 +90,12 @@ struct render_args {
   //           are cut into that many ranges taken by different lanes, so that the pixels that turn
   //           out expensive hold the end of the launch up for a fraction of their cost only; every
   //           sample's radiance goes to split_samples (row = rect pixel), the segment counts are
-  //           added up in carry_key, and rt_probe_sum_kernel forms what pass 1 would have left
+  //           added up in carry_cost, and rt_probe_sum_kernel forms what pass 1 would have left
   int pass;
   int sweeps;
   float* carry_colour;         // 3 floats per rect pixel
   uint32_t* carry_rng;
-  uint32_t* carry_key;         // pass 1 writes the sort key (small = expensive) ...
-  uint32_t* carry_idx;         // ... and the rect-pixel index it belongs to
+  uint32_t* carry_cost;        // segments the probe spent on the rect pixel (pass 1 stores, pass 3 adds)
   // Pass 2 takes jobs, not pixels: a pixel so expensive that it alone would outlast the rest of
   // the launch is cut into several sample ranges.  The lanes working on such a pixel store every
   // sample's radiance, and rt_sum_split_kernel adds them up in sample order afterwards, which
@@ -330,15 +329,14 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
   // probe pass parks it (with the RNG state and a cost key) for pass 2.
   auto close_pixel = [&]() {
     if (A.pass == 3) {
-      atomicAdd(A.carry_key + rect_pixel, pixel_segments);
+      atomicAdd(A.carry_cost + rect_pixel, pixel_segments);
     } else if (A.pass == 1) {
       float* dst = A.carry_colour + 3 * (size_t)rect_pixel;
       dst[0] = colour.x;
       dst[1] = colour.y;
       dst[2] = colour.z;
       A.carry_rng[rect_pixel] = rng;
-      A.carry_key[rect_pixel] = 4095u - min(pixel_segments, 4095u);
-      A.carry_idx[rect_pixel] = rect_pixel;
+      A.carry_cost[rect_pixel] = pixel_segments;
     } else if (split_row == RT_JOB_WHOLE) {
       float* dst = A.accum + 3 * (size_t)pixel;
       dst[0] = colour.x;
@@ -545,23 +543,23 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
 }
 
 // ---- job planning for the main pass of two-pass rendering --------------------
-// keys[i] (sorted ascending) = 4095 - segments the probe pass spent on pixel order[i].
+// cost[p] = segments the probe pass spent on rect pixel p; order[i] = the pixel at sorted position i.
 
-__global__ __launch_bounds__(256) void rt_plan_cost_kernel(const uint32_t* keys, uint32_t n, unsigned long long* total) {
+__global__ __launch_bounds__(256) void rt_plan_cost_kernel(const uint32_t* cost, uint32_t n, unsigned long long* total) {
   unsigned long long sum = 0;
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) sum += 4095u - keys[i];
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) sum += cost[i];
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
   if ((threadIdx.x & 63) == 0 && sum != 0) atomicAdd(total, sum);
 }
 
-// Jobs of pixel i: its share of the measured cost in units of 1/(8 * lanes) of the total, so that no
-// job is longer than an eighth of a lane's fair share; at least min_samples samples each, at most
-// max_parts, only the first max_split pixels (the most expensive ones) and only when splittable.
-RT_DEV uint32_t plan_parts(uint32_t key, unsigned long long total, uint32_t lanes, uint32_t i, uint32_t max_split, int samples,
-                           int splittable) {
+// Jobs of the pixel at sorted position i: its share of the measured cost in units of 1/lanes of the
+// total (`lanes` arrives multiplied by the fineness factor), so that no job is longer than that
+// fraction of a lane's fair share; at least 8 samples each, at most 64 parts, only the first
+// max_split positions (the most expensive pixels) and only when splittable.
+RT_DEV uint32_t plan_parts(unsigned long long cost, unsigned long long total, uint32_t lanes, uint32_t i, uint32_t max_split,
+                           int samples, int splittable) {
   if (!splittable || i >= max_split || total == 0ull) return 1u;
-  const unsigned long long cost = 4095u - key;
-  unsigned long long parts = (cost * lanes + total - 1ull) / total;  // `lanes` arrives multiplied by the fineness factor
+  unsigned long long parts = (cost * lanes + total - 1ull) / total;
   const unsigned long long most = (unsigned long long)max(samples / 8, 1);
   parts = parts < 1ull ? 1ull : parts;
   parts = parts > 64ull ? 64ull : parts;
@@ -569,11 +567,11 @@ RT_DEV uint32_t plan_parts(uint32_t key, unsigned long long total, uint32_t lane
   return (uint32_t)parts;
 }
 
-__global__ __launch_bounds__(256) void rt_plan_count_kernel(const uint32_t* keys, uint32_t n, const unsigned long long* total,
-                                                           uint32_t lanes, uint32_t max_split, int samples, int splittable,
-                                                           uint32_t* parts) {
+__global__ __launch_bounds__(256) void rt_plan_count_kernel(const uint32_t* cost, const uint32_t* order, uint32_t n,
+                                                           const unsigned long long* total, uint32_t lanes, uint32_t max_split,
+                                                           int samples, int splittable, uint32_t* parts) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) parts[i] = plan_parts(keys[i], *total, lanes, i, max_split, samples, splittable);
+  if (i < n) parts[i] = plan_parts(cost[order[i]], *total, lanes, i, max_split, samples, splittable);
 }
 
 // first[i] = exclusive prefix sum of parts.  Writes the jobs of pixel i and, from the last pixel, the job count.
@@ -611,12 +609,10 @@ __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order
 }
 
 // After a probe in sweeps (pass 3): the pixel's probe samples are added in sample order onto what
-// earlier sample ranges left in the image, exactly as one lane would have added them; the summed
-// segment count becomes the sort key (small = expensive).
+// earlier sample ranges left in the image, exactly as one lane would have added them.
 __global__ __launch_bounds__(256) void rt_probe_sum_kernel(uint32_t n_rect, const float* probe_samples, int n_probe, int tile_x0,
                                                           int tile_y0, int tile_w, int width, const float* accum,
-                                                          float* carry_colour, uint32_t* carry_rng, uint32_t* carry_key,
-                                                          uint32_t* carry_idx) {
+                                                          float* carry_colour, uint32_t* carry_rng) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_rect) return;
   const int x = tile_x0 + (int)(i % (uint32_t)tile_w), y = tile_y0 + (int)(i / (uint32_t)tile_w);
@@ -628,8 +624,24 @@ __global__ __launch_bounds__(256) void rt_probe_sum_kernel(uint32_t n_rect, cons
   carry_colour[3 * (size_t)i + 1] = colour.y;
   carry_colour[3 * (size_t)i + 2] = colour.z;
   carry_rng[i] = 0u;  // the counter RNG re-keys every sample
-  carry_key[i] = 4095u - min(carry_key[i], 4095u);
-  carry_idx[i] = i;
+}
+
+// Sort key of the main pass: the probe's cost in a few steps per power of two, most
+// expensive first, and below it the pixel's 8x8 tile.  Pixels of about the same cost then stay
+// together tile by tile, so that the lanes of a wave — which take consecutive jobs — follow
+// neighbouring rays through the same part of the scene, where a sort by cost alone would scatter
+// them over the image.
+__global__ __launch_bounds__(256) void rt_sort_key_kernel(uint32_t n_rect, int tile_w, int log2_steps, int log2_tile, const uint32_t* carry_cost,
+                                                         uint32_t* key, uint32_t* idx) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rect) return;
+  const uint32_t x = i % (uint32_t)tile_w, y = i / (uint32_t)tile_w, tiles_x = (((uint32_t)tile_w - 1u) >> log2_tile) + 1u;
+  uint32_t tile = (y >> log2_tile) * tiles_x + (x >> log2_tile);
+  while (tile >> 20) tile >>= 1;  // (images beyond a million tiles: neighbouring tiles share a value)
+  // 2^log2_steps levels per octave (log2_steps <= 6: fewer than 2048 levels over the 23 octaves)
+  const uint32_t level = (__float_as_uint((float)(min(carry_cost[i], 0x7FFFFFu) + 1u)) >> (23 - log2_steps)) - (127u << log2_steps);
+  key[i] = ((2047u - min(level, 2047u)) << 20) | tile;
+  idx[i] = i;
 }
 
 struct trace_args {
