@@ -393,7 +393,7 @@ int split_fineness() {
 // rendering (RT_TWO_PASS=0 in the environment turns it off, for comparison).
 // The probe takes an eighth of the samples, between 8 and a cap: 32 when it runs in sweeps (counter RNG: short jobs
 // in tile order are about as efficient as the sorted main pass, and a longer probe measures costs better), 16 when
-// every pixel's probe is one job.  RT_PROBE_SAMPLES overrides the cap, for tuning (the split of a frame into probe
+// every pixel's probe is one job.  RT_PROBE_SAMPLES sets the length itself, for tuning (the split of a frame into probe
 // and main pass never changes the image).  Two-pass rendering needs at least 64 samples.
 constexpr int kMinTwoPassSamples = 64;
 int probe_samples(int n_samples, bool swept) {
@@ -402,11 +402,11 @@ int probe_samples(int n_samples, bool swept) {
     int x = e ? atoi(e) : 0;
     return x < 0 ? 0 : (x > 256 ? 256 : x);
   }();
-  const int most = cap > 0 ? cap : (swept ? 32 : 16);
+  if (cap > 0) return cap < n_samples - 8 ? cap : n_samples - 8;  // at least 8 samples stay for the main pass
+  const int most = swept ? 32 : 16;
   int n = n_samples / 8;
   n = n < 8 ? 8 : n;
-  n = n > most ? most : n;
-  return n < n_samples ? n : n_samples;
+  return n > most ? most : n;
 }
 bool two_pass_enabled() {
   static bool v = [] {
