@@ -280,3 +280,21 @@ def test_render_with_a_tree_too_big_for_lds(renderer, scale, lookfrom_z):
     acc, oc = oracle.render(scene, p, threads=16)
     assert_same_f32(frames[rt.ACCEL_LBVH], oracle.resolve(acc, 4)[0], "tree vs CPU restatement")
     assert c["hits"] == oc["hits"] and c["segments"] == oc["segments"]
+
+
+def test_batch_result_does_not_depend_on_ray_order(renderer):
+    """Lanes of a group fetch parts of each other's nodes and rays are handed out in chunks: neither may couple a
+    ray's answer to its neighbours.  The same rays sorted by origin cell give the same answers, permuted."""
+    scene = rt.build_scene(rt.SCENE_CLOUD, n=60000, seed=11)
+    o, d = rt.gen_rays(123, 0, 300000)
+    renderer.upload(scene, rt.ACCEL_LBVH)
+    a = renderer.trace(o, d)
+    cell = np.clip(((o + 600.0) / 1200.0 * 32).astype(np.int64), 0, 31)
+    order = np.argsort((cell[:, 0] * 32 + cell[:, 1]) * 32 + cell[:, 2], kind="stable")
+    b = renderer.trace(o[order], d[order])
+    assert (a[0] >= 0).sum() > 1000
+    assert np.array_equal(b[0], a[0][order])
+    assert_same_f32(b[1], a[1][order], "t")
+    assert_same_f32(b[2], a[2][order], "normal")
+    c = renderer.trace(o[order], d[order])
+    assert np.array_equal(b[0], c[0]) and np.array_equal(_bits(b[1]), _bits(c[1]))
