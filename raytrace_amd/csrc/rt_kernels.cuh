@@ -351,7 +351,10 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
     if (split_row == RT_JOB_WHOLE) {
       colour = colour + alb;
     } else {
-      float* dst = A.split_samples + ((size_t)split_row * (size_t)A.main_samples + (size_t)(s - P.sample_begin)) * 3;
+      // rows of samples for the split pixels of the main pass; sample-major for a probe in sweeps, where every
+      // pixel has a row and neighbouring lanes hold neighbouring pixels
+      float* dst = A.split_samples + (A.pass == 3 ? (size_t)(s - P.sample_begin) * ((size_t)tw * (size_t)th) + (size_t)split_row
+                                                  : (size_t)split_row * (size_t)A.main_samples + (size_t)(s - P.sample_begin)) * 3;
       dst[0] = alb.x;
       dst[1] = alb.y;
       dst[2] = alb.z;
@@ -618,8 +621,10 @@ __global__ __launch_bounds__(256) void rt_probe_sum_kernel(uint32_t n_rect, cons
   const int x = tile_x0 + (int)(i % (uint32_t)tile_w), y = tile_y0 + (int)(i / (uint32_t)tile_w);
   const float* base = accum + 3 * ((size_t)y * (size_t)width + (size_t)x);
   f3 colour = mk3(base[0], base[1], base[2]);
-  const float* src = probe_samples + (size_t)i * (size_t)n_probe * 3;
-  for (int s = 0; s < n_probe; s++) colour = colour + mk3(src[3 * s], src[3 * s + 1], src[3 * s + 2]);
+  for (int s = 0; s < n_probe; s++) {  // sample-major buffer: consecutive threads read consecutive pixels
+    const float* src = probe_samples + ((size_t)s * n_rect + i) * 3;
+    colour = colour + mk3(src[0], src[1], src[2]);
+  }
   carry_colour[3 * (size_t)i] = colour.x;
   carry_colour[3 * (size_t)i + 1] = colour.y;
   carry_colour[3 * (size_t)i + 2] = colour.z;
