@@ -67,7 +67,7 @@ struct dev_buf {
 };
 
 // Memory for the per-sample radiance of pixels whose main pass is cut into several jobs.
-constexpr size_t kSplitBudgetBytes = (size_t)1 << 30;
+constexpr size_t kSplitBudgetBytes = (size_t)2 << 30;
 // The same for the probe pass in sweeps (every pixel's probe samples): beyond this the probe runs unsplit.
 constexpr size_t kProbeBudgetBytes = (size_t)4 << 30;
 // Largest dynamic LDS a launch may ask for (the CU has 160 KiB).
@@ -368,6 +368,16 @@ int cost_steps_log2() {
   return v;
 }
 
+// How many of the most expensive pixels the main pass may cut into several jobs (RT_SPLIT_ROWS overrides; the
+// memory budget for their per-sample radiance limits it further).
+int split_rows() {
+  static int v = [] {
+    const char* e = getenv("RT_SPLIT_ROWS");
+    return e ? atoi(e) : -1;  // negative: chosen from the frame size
+  }();
+  return v;
+}
+
 // Sweeps of the probe pass (RT_PROBE_SWEEPS overrides, 1 = unsplit probe).
 int probe_sweeps() {
   static int v = [] {
@@ -657,7 +667,10 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       // a job should be a small fraction (1 / split_fineness()) of a lane's fair share of the frame
       const uint32_t lanes = (uint32_t)c->n_cu * 1024u * (uint32_t)split_fineness();
       size_t want = kSplitBudgetBytes / ((size_t)main_samples * 3 * sizeof(float));
-      const uint32_t max_split = (uint32_t)(want > 65536 ? 65536 : want);
+      // frames with fewer than four pixels per lane balance only if most pixels may be cut (measured: 960x540
+      // +15 %); larger frames need the most expensive pixels only, and more rows just add traffic
+      const size_t row_cap = split_rows() >= 0 ? (size_t)split_rows() : (n_rect < (size_t)c->n_cu * 4096 ? n_rect : (size_t)65536);
+      const uint32_t max_split = (uint32_t)(want > row_cap ? row_cap : want);
       const int splittable = p->rng_mode == RT_RNG_COUNTER && max_split > 0 ? 1 : 0;
       HIP_TRY(c->plan_parts.resize(n));
       HIP_TRY(c->plan_first.resize(n));
