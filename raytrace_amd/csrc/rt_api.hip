@@ -605,7 +605,25 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   const bool two_pass = two_pass_enabled() && n_samples >= kMinTwoPassSamples && n_rect >= 16384;
   HIP_TRY(hipEventRecord(c->ev_k0, c->stream));
   hipError_t e;
-  if (!two_pass) {
+  // Few samples, counter RNG: the frame as a whole is rendered in sweeps (short jobs in tile order, per-sample
+  // radiance summed in order afterwards) — a pixel per job would end with the expensive pixels' lanes working alone.
+  const bool whole_in_sweeps = !two_pass && two_pass_enabled() && p->rng_mode == RT_RNG_COUNTER && probe_sweeps() > 1 &&
+                               n_samples >= 2 && n_rect >= 16384 &&
+                               n_rect * (size_t)n_samples * 3 * sizeof(float) <= kProbeBudgetBytes;
+  if (whole_in_sweeps) {
+    HIP_TRY(c->probe_samples.resize(n_rect * (size_t)n_samples * 3));
+    render_args sw = a;
+    sw.pass = 3;
+    sw.sweeps = probe_sweeps() < n_samples ? probe_sweeps() : n_samples;
+    sw.split_samples = c->probe_samples.p;
+    sw.main_samples = n_samples;
+    e = launch(sw, p);
+    if (e == hipSuccess) {
+      rt_probe_sum_kernel<<<(unsigned)((n_rect + 255) / 256), 256, 0, c->stream>>>(
+          (uint32_t)n_rect, c->probe_samples.p, n_samples, p->tile_x0, p->tile_y0, tw, p->width, c->accum(), nullptr, nullptr);
+      e = hipGetLastError();
+    }
+  } else if (!two_pass) {
     e = launch(a, p);
   } else {
     HIP_TRY(c->carry_colour.resize(3 * n_rect));

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
   // probe pass parks it (with the RNG state and a cost key) for pass 2.
   auto close_pixel = [&]() {
     if (A.pass == 3) {
-      atomicAdd(A.carry_cost + rect_pixel, pixel_segments);
+      if (A.carry_cost) atomicAdd(A.carry_cost + rect_pixel, pixel_segments);
     } else if (A.pass == 1) {
       float* dst = A.carry_colour + 3 * (size_t)rect_pixel;
       dst[0] = colour.x;
@@ -611,24 +611,27 @@ __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order
   dst[2] = colour.z;
 }
 
-// After a probe in sweeps (pass 3): the pixel's probe samples are added in sample order onto what
-// earlier sample ranges left in the image, exactly as one lane would have added them.
+// After a pass in sweeps (pass 3): the pixel's samples are added in sample order onto what earlier
+// sample ranges left in the image, exactly as one lane would have added them.  The sum goes to the
+// carry arrays (a probe: the main pass continues from it) or, with carry_colour null, back into the
+// image (a frame rendered in sweeps as a whole).
 __global__ __launch_bounds__(256) void rt_probe_sum_kernel(uint32_t n_rect, const float* probe_samples, int n_probe, int tile_x0,
-                                                          int tile_y0, int tile_w, int width, const float* accum,
+                                                          int tile_y0, int tile_w, int width, float* accum,
                                                           float* carry_colour, uint32_t* carry_rng) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_rect) return;
   const int x = tile_x0 + (int)(i % (uint32_t)tile_w), y = tile_y0 + (int)(i / (uint32_t)tile_w);
-  const float* base = accum + 3 * ((size_t)y * (size_t)width + (size_t)x);
+  float* base = accum + 3 * ((size_t)y * (size_t)width + (size_t)x);
   f3 colour = mk3(base[0], base[1], base[2]);
   for (int s = 0; s < n_probe; s++) {  // sample-major buffer: consecutive threads read consecutive pixels
     const float* src = probe_samples + ((size_t)s * n_rect + i) * 3;
     colour = colour + mk3(src[0], src[1], src[2]);
   }
-  carry_colour[3 * (size_t)i] = colour.x;
-  carry_colour[3 * (size_t)i + 1] = colour.y;
-  carry_colour[3 * (size_t)i + 2] = colour.z;
-  carry_rng[i] = 0u;  // the counter RNG re-keys every sample
+  float* dst = carry_colour ? carry_colour + 3 * (size_t)i : base;
+  dst[0] = colour.x;
+  dst[1] = colour.y;
+  dst[2] = colour.z;
+  if (carry_rng) carry_rng[i] = 0u;  // the counter RNG re-keys every sample
 }
 
 // Sort key of the main pass: the probe's cost in a few steps per power of two, most

@@ -298,3 +298,20 @@ def test_batch_result_does_not_depend_on_ray_order(renderer):
     assert_same_f32(b[2], a[2][order], "normal")
     c = renderer.trace(o[order], d[order])
     assert np.array_equal(b[0], c[0]) and np.array_equal(_bits(b[1]), _bits(c[1]))
+
+
+@pytest.mark.parametrize("accel", [rt.ACCEL_LBVH, rt.ACCEL_LINEAR])
+def test_few_samples_in_sweeps_match_oracle(renderer, accel):
+    """Enough pixels but too few samples for a probe: with the counter RNG the whole frame is rendered as short
+    jobs whose per-sample radiance is summed in order afterwards.  Rendered in two sample ranges onto the same
+    image, so that the second sum starts from what the first left."""
+    scene = rt.build_scene(rt.SCENE_RANDOM_SPHERES)
+    cam = rt.scene_camera(rt.SCENE_RANDOM_SPHERES)
+    renderer.upload(scene, accel)
+    renderer.clear()
+    for s0, n in ((0, 5), (5, 3)):
+        renderer.render(rt.make_params(cam, 160, 104, n, rng_mode=rt.RNG_COUNTER, sample_begin=s0))
+    lin, _ = renderer.readback(rgb8=False)
+    # the CPU restatement adds the eight samples in order in one go: the same sum
+    acc, _ = oracle.render(scene, rt.make_params(cam, 160, 104, 8, rng_mode=rt.RNG_COUNTER), threads=8)
+    assert_same_f32(lin, oracle.resolve(acc, 8)[0], "linear radiance")
