@@ -76,6 +76,8 @@ constexpr size_t kMaxLdsBytes = 160 * 1024;
 constexpr size_t kLdsTreeBudget = 64 * 1024;
 // Spheres with a radius above kBigFactor x the median radius stay out of the
 // tree (at most kMaxBig of them) and are tested exactly for every ray.
+// The noise texture's gradient table covers the lattice points [-kPerlinHalf, kPerlinHalf)^2 (134 MB).
+constexpr int kPerlinHalf = 2048;
 constexpr float kBigFactor = 8.0f;
 constexpr int kMaxBig = 8;
 
@@ -111,6 +113,8 @@ struct rt_ctx {
   dev_buf<float> inv_r;
   dev_buf<int32_t> sph_mat, mat_type;
   dev_buf<float4> mat_a;
+  dev_buf<float2> perlin_grad;  // gradient table of the noise texture, built with the first scene that uses it
+  bool have_noise = false;
   // hierarchy
   int search = SEARCH_LINEAR;
   int n_big = 0, n_leaf = 0, n_nodes = 0, root = 0, depth = 0;
@@ -161,6 +165,8 @@ struct rt_ctx {
     s.sph_mat = sph_mat.p;
     s.mat_a = mat_a.p;
     s.mat_type = mat_type.p;
+    s.noise.grad = have_noise ? perlin_grad.p : nullptr;
+    s.noise.half = kPerlinHalf;
     s.n_big = n_big;
     s.big_sph = big_sph.p;
     s.big_idx = big_idx.p;
@@ -782,7 +788,7 @@ void rt_destroy(rt_ctx* c) {
   c->sph.release(); c->inv_r.release(); c->sph_mat.release(); c->mat_type.release(); c->mat_a.release();
   c->big_sph.release(); c->big_idx.release(); c->tree_sph.release(); c->tree_r.release(); c->tree_orig.release();
   c->nodes.release(); c->leaf_sph.release(); c->leaf_r.release(); c->leaf_idx.release();
-  c->accum_own.release(); c->seed_tex.release(); c->queue.release(); c->counters.release(); c->ovf.release(); c->build.release();
+  c->accum_own.release(); c->seed_tex.release(); c->queue.release(); c->counters.release(); c->ovf.release(); c->build.release(); c->perlin_grad.release();
   c->carry_colour.release(); c->carry_rng.release(); c->carry_cost.release(); c->carry_key.release(); c->carry_idx.release();
   c->plan_parts.release(); c->plan_first.release(); c->plan_counts.release(); c->plan_total.release();
   c->plan_jobs.release(); c->split_samples.release(); c->probe_samples.release(); c->scan_temp.release();
@@ -841,6 +847,14 @@ int rt_scene_upload(rt_ctx* c, const void* spheres_std140, int n_spheres, const 
   HIP_TRY(c->sph_mat.upload(sph_mat, c->stream));
   HIP_TRY(c->mat_type.upload(mat_type, c->stream));
   HIP_TRY(c->mat_a.upload(mat_a, c->stream));
+  c->have_noise = false;
+  for (size_t i = 0; i < nm; i++) c->have_noise = c->have_noise || mat_type[i] == RT_MAT_PERLIN_LAMBERTIAN;
+  if (c->have_noise && !c->perlin_grad.p) {  // the table does not depend on the scene: built once per context
+    const size_t side = 2 * (size_t)kPerlinHalf;
+    HIP_TRY(c->perlin_grad.resize(side * side));
+    rt_perlin_table_kernel<<<(unsigned)((side * side + 255) / 256), 256, 0, c->stream>>>(c->perlin_grad.p, kPerlinHalf);
+    HIP_TRY(hipGetLastError());
+  }
 
   // Hierarchy input: the few spheres far larger than the rest go to an exact
   // pre-test list, the others into the tree.

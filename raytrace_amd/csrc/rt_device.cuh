@@ -206,9 +206,15 @@ RT_DEV void perlin_gradient(int ix, int iy, float& gx, float& gy) {  // perlin.h
   gy = (float)s;
 }
 
-RT_DEV float perlin_dot_grid(int ix, int iy, float x, float y) {  // perlin.h:46-56
-  float gx, gy;
-  perlin_gradient(ix, iy, gx, gy);
+// Gradients of the lattice points [-half, half)^2, computed once per scene by perlin_gradient itself
+// (so a table entry is bit for bit what the function returns): a gradient costs a double-precision
+// sincos, four per noise value.  Points outside the window are computed on the spot.
+struct perlin_table {
+  const float2* grad;  // (iy + half) * 2 * half + (ix + half); null: no table
+  int half;
+};
+
+RT_DEV float perlin_dot(float gx, float gy, int ix, int iy, float x, float y) {  // perlin.h:46-56
   float dx = x - (float)ix;
   float dy = y - (float)iy;
   return dx * gx + dy * gy;
@@ -216,18 +222,32 @@ RT_DEV float perlin_dot_grid(int ix, int iy, float x, float y) {  // perlin.h:46
 
 RT_DEV float perlin_lerp(float a0, float a1, float w) { return (a1 - a0) * w + a0; }  // perlin.h:11-16
 
-RT_DEV float perlin2(float x, float y) {  // perlin.h:59-85
+RT_DEV float perlin2(float x, float y, perlin_table tab) {  // perlin.h:59-85
   int x0 = (int)floorf(x);
   int x1 = x0 + 1;
   int y0 = (int)floorf(y);
   int y1 = y0 + 1;
   float sx = x - (float)x0;
   float sy = y - (float)y0;
-  float n0 = perlin_dot_grid(x0, y0, x, y);
-  float n1 = perlin_dot_grid(x1, y0, x, y);
+  float2 g00, g10, g01, g11;
+  if (tab.grad != nullptr && x0 >= -tab.half && x1 < tab.half && y0 >= -tab.half && y1 < tab.half) {
+    const float2* row0 = tab.grad + (size_t)(y0 + tab.half) * (size_t)(2 * tab.half) + (size_t)(x0 + tab.half);
+    const float2* row1 = row0 + 2 * tab.half;
+    g00 = row0[0];
+    g10 = row0[1];
+    g01 = row1[0];
+    g11 = row1[1];
+  } else {
+    perlin_gradient(x0, y0, g00.x, g00.y);
+    perlin_gradient(x1, y0, g10.x, g10.y);
+    perlin_gradient(x0, y1, g01.x, g01.y);
+    perlin_gradient(x1, y1, g11.x, g11.y);
+  }
+  float n0 = perlin_dot(g00.x, g00.y, x0, y0, x, y);
+  float n1 = perlin_dot(g10.x, g10.y, x1, y0, x, y);
   float ix0 = perlin_lerp(n0, n1, sx);
-  n0 = perlin_dot_grid(x0, y1, x, y);
-  n1 = perlin_dot_grid(x1, y1, x, y);
+  n0 = perlin_dot(g01.x, g01.y, x0, y1, x, y);
+  n1 = perlin_dot(g11.x, g11.y, x1, y1, x, y);
   float ix1 = perlin_lerp(n0, n1, sx);
   float value = perlin_lerp(ix0, ix1, sy);
   return (float)(((double)value * 0.5) + 0.5);
@@ -262,8 +282,8 @@ struct hit_rec {
 // ahead of the branch, so that lanes with different materials share the
 // rejection loop (each lane's own draw sequence is unchanged).
 template <int RNG, bool COUNTED>
-RT_DEV bool shade_hit(const hit_rec& h, int type, float param1, f3 m_albedo, f3& dir, f3& albedo, uint32_t& rng,
-                      lane_counters& k) {
+RT_DEV bool shade_hit(const hit_rec& h, int type, float param1, f3 m_albedo, perlin_table noise, f3& dir, f3& albedo,
+                      uint32_t& rng, lane_counters& k) {
 #ifdef RT_ABL_LAMBERT_ONLY  // timing experiments only: wrong results
   type = RT_MAT_LAMBERTIAN;
 #endif
@@ -286,7 +306,7 @@ RT_DEV bool shade_hit(const hit_rec& h, int type, float param1, f3 m_albedo, f3&
       albedo = albedo * m_albedo;
     } else {
       RT_COUNT(k, perlin, 1);
-      float n = perlin2(param1 * h.point.x, param1 * h.point.z);
+      float n = perlin2(param1 * h.point.x, param1 * h.point.z, noise);
       albedo = albedo * (m_albedo * n);
     }
     return true;

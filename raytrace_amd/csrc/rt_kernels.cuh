@@ -415,7 +415,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
         const int type = sv.mat_type[h.mat];
         next_o = h.point;  // fs:211-212
         count = count + 1u;
-        cont = shade_hit<RNG, COUNTED>(h, type, ma.w, mk3(ma.x, ma.y, ma.z), d, alb, rng, k);
+        cont = shade_hit<RNG, COUNTED>(h, type, ma.w, mk3(ma.x, ma.y, ma.z), sc.noise, d, alb, rng, k);
         RT_CLK_STOP(1);
       } else {  // fs:217-218
         alb = sky_radiance(d, alb);
@@ -745,6 +745,15 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
     }
   }
   flush_counters<COUNTED>(A.counters, k);
+}
+
+// Fills the gradient table of the noise texture: one lattice point per thread.
+__global__ __launch_bounds__(256) void rt_perlin_table_kernel(float2* grad, int half) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, side = (size_t)(2 * half);
+  if (i >= side * side) return;
+  float gx, gy;
+  perlin_gradient((int)(i % side) - half, (int)(i / side) - half, gx, gy);
+  grad[i] = make_float2(gx, gy);
 }
 
 // End of the shader's main (fs:135-140) and the RGB8 store: mean over the

@@ -26,6 +26,7 @@ struct scene_dev {
   const int32_t* sph_mat;   // material slot
   const float4* mat_a;      // (albedo.r, albedo.g, albedo.b, param1)
   const int32_t* mat_type;
+  perlin_table noise;       // gradient table of the noise-textured material (null without one)
   // --- hierarchy (unused by the linear scan) ---
   // Spheres much larger than the rest are kept out of the tree and tested
   // exactly for every ray: their boxes would swallow the whole tree.
