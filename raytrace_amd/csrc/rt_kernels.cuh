@@ -23,6 +23,9 @@ enum {
 #ifndef RT_TRACE_WAVES
 #define RT_TRACE_WAVES 4
 #endif
+#ifndef RT_JOB_CHUNK
+#define RT_JOB_CHUNK 64u   // pixels / jobs a wave takes from the queue per atomic (more when more lanes ask at once)
+#endif
 #ifndef RT_LINEAR_WAVES
 #define RT_LINEAR_WAVES 4
 #endif
@@ -243,14 +246,16 @@ RT_DEV Q take_items(bool need, Q* queue, Q& pool_next, Q& pool_end) {
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_need, 0u));
     const Q avail = pool_end - pool_next;
     if (avail < (Q)n_need) {
+      // a chunk, or as much as the lanes ask for beyond what is left of the old one if that is more
+      const Q amount = (Q)n_need - avail > (Q)CHUNK ? (Q)n_need - avail : (Q)CHUNK;
       Q fresh = 0;
-      if ((threadIdx.x & 63) == 0) fresh = atomicAdd(queue, (Q)CHUNK);
+      if ((threadIdx.x & 63) == 0) fresh = atomicAdd(queue, amount);
       fresh = sizeof(Q) == 8 ? (Q)(((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)((unsigned long long)fresh >> 32)) << 32) |
                                    __builtin_amdgcn_readfirstlane((uint32_t)fresh))
                              : (Q)__builtin_amdgcn_readfirstlane((uint32_t)fresh);
       item = (Q)rank < avail ? pool_next + rank : fresh + ((Q)rank - avail);
       pool_next = fresh + ((Q)n_need - avail);
-      pool_end = fresh + (Q)CHUNK;
+      pool_end = fresh + amount;
     } else {
       item = pool_next + rank;
       pool_next += (Q)n_need;
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
     }
     RT_CLK_STOP(3);
     const bool need_pixel = ready && !start_segment && !have;
-    const uint32_t item = take_items<unsigned int, 64u>(need_pixel, A.queue, pool_next, pool_end);
+    const uint32_t item = take_items<unsigned int, RT_JOB_CHUNK>(need_pixel, A.queue, pool_next, pool_end);
     if (ready && !start_segment) {
       if (!have) {  // the next pixel
         if (item >= total_items) {
