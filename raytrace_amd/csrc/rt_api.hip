@@ -139,6 +139,11 @@ struct rt_ctx {
   dev_buf<uint32_t> seed_tex;
   dev_buf<unsigned long long> queue;  // work-queue head of the running launch
   lbvh_scratch build;
+  // rt_trace_batch (host buffers): two sets of device chunk buffers, copy streams and events, made on first use
+  hipStream_t copy_in = nullptr, copy_out = nullptr;
+  hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_run[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+  dev_buf<float> tb_o[2], tb_d[2], tb_t[2], tb_n[2];
+  dev_buf<int32_t> tb_id[2];
   dev_buf<uint32_t> ovf;              // traversal-stack overflow of the running launch (HBM-resident trees)
   // two-pass rendering: per-pixel carry of the probe pass and the sorted pixel order
   dev_buf<float> carry_colour;
@@ -797,6 +802,14 @@ void rt_destroy(rt_ctx* c) {
   if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
   if (c->ev_b0) (void)hipEventDestroy(c->ev_b0);
   if (c->ev_b1) (void)hipEventDestroy(c->ev_b1);
+  for (int b = 0; b < 2; b++) {
+    if (c->ev_in[b]) (void)hipEventDestroy(c->ev_in[b]);
+    if (c->ev_run[b]) (void)hipEventDestroy(c->ev_run[b]);
+    if (c->ev_out[b]) (void)hipEventDestroy(c->ev_out[b]);
+    c->tb_o[b].release(); c->tb_d[b].release(); c->tb_t[b].release(); c->tb_n[b].release(); c->tb_id[b].release();
+  }
+  if (c->copy_in) (void)hipStreamDestroy(c->copy_in);
+  if (c->copy_out) (void)hipStreamDestroy(c->copy_out);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1071,37 +1084,63 @@ int rt_trace_batch_device(rt_ctx* c, const float* o_xyz, const float* d_xyz, siz
   return RT_OK;
 }
 
+// Host buffers: the batch goes through the GPU in chunks, with the copy in of chunk k+1 and the copy out of chunk
+// k-1 running beside the kernel of chunk k (two sets of device buffers, one stream per direction).
 int rt_trace_batch(rt_ctx* c, const float* o_xyz, const float* d_xyz, size_t n, int32_t* id, float* t, float* nrm) {
   int rc = check_ctx(c);
   if (rc) return rc;
+  if (!c->have_scene) return fail(RT_ERR_STATE, "rt_trace_batch before rt_scene_upload");
   if (n == 0) return RT_OK;
   if (!o_xyz || !d_xyz || !id || !t || !nrm) return fail(RT_ERR_INVALID, "null ray or result pointer");
-  dev_buf<float> d_o, d_d, d_t, d_n;
-  dev_buf<int32_t> d_id;
-  auto cleanup = [&]() { d_o.release(); d_d.release(); d_t.release(); d_n.release(); d_id.release(); };
-  hipError_t e = d_o.resize(3 * n);
-  if (e == hipSuccess) e = d_d.resize(3 * n);
-  if (e == hipSuccess) e = d_t.resize(n);
-  if (e == hipSuccess) e = d_n.resize(3 * n);
-  if (e == hipSuccess) e = d_id.resize(n);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_o.p, o_xyz, 3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_d.p, d_xyz, 3 * n * sizeof(float), hipMemcpyHostToDevice, c->stream);
-  if (e != hipSuccess) {
-    cleanup();
-    return fail(RT_ERR_DEVICE, "ray batch staging: %s", hipGetErrorString(e));
+  constexpr size_t kChunk = (size_t)1 << 22;  // rays per chunk: 96 MB in, 80 MB out
+  const size_t chunk = n < kChunk ? n : kChunk;
+  if (!c->copy_in) HIP_TRY(hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking));
+  if (!c->copy_out) HIP_TRY(hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking));
+  for (int b = 0; b < 2; b++) {
+    if (!c->ev_in[b]) HIP_TRY(hipEventCreateWithFlags(&c->ev_in[b], hipEventDisableTiming));
+    if (!c->ev_run[b]) HIP_TRY(hipEventCreateWithFlags(&c->ev_run[b], hipEventDisableTiming));
+    if (!c->ev_out[b]) HIP_TRY(hipEventCreateWithFlags(&c->ev_out[b], hipEventDisableTiming));
+    HIP_TRY(c->tb_o[b].resize(3 * chunk));
+    HIP_TRY(c->tb_d[b].resize(3 * chunk));
+    HIP_TRY(c->tb_t[b].resize(chunk));
+    HIP_TRY(c->tb_n[b].resize(3 * chunk));
+    HIP_TRY(c->tb_id[b].resize(chunk));
   }
-  rc = rt_trace_batch_device(c, d_o.p, d_d.p, n, d_id.p, d_t.p, d_n.p, 0);
-  if (rc == RT_OK) {
-    e = hipMemcpyAsync(id, d_id.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(t, d_t.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(nrm, d_n.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, "ray batch readback: %s", hipGetErrorString(e));
-  } else {
-    (void)hipStreamSynchronize(c->stream);
+  const size_t n_chunks = (n + chunk - 1) / chunk;
+  auto copy_out = [&](size_t k) -> hipError_t {  // results of chunk k to the caller, after its kernel
+    const int b = (int)(k & 1);
+    const size_t first = k * chunk, m = n - first < chunk ? n - first : chunk;
+    hipError_t e = hipStreamWaitEvent(c->copy_out, c->ev_run[b], 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(id + first, c->tb_id[b].p, m * sizeof(int32_t), hipMemcpyDeviceToHost, c->copy_out);
+    if (e == hipSuccess) e = hipMemcpyAsync(t + first, c->tb_t[b].p, m * sizeof(float), hipMemcpyDeviceToHost, c->copy_out);
+    if (e == hipSuccess) e = hipMemcpyAsync(nrm + 3 * first, c->tb_n[b].p, 3 * m * sizeof(float), hipMemcpyDeviceToHost, c->copy_out);
+    if (e == hipSuccess) e = hipEventRecord(c->ev_out[b], c->copy_out);
+    return e;
+  };
+  hipError_t e = hipSuccess;
+  for (size_t k = 0; k < n_chunks && e == hipSuccess && rc == RT_OK; k++) {
+    const int b = (int)(k & 1);
+    const size_t first = k * chunk, m = n - first < chunk ? n - first : chunk;
+    // the rays of chunk k-2 were read by its kernel; its results have left the result buffers
+    if (k >= 2) e = hipStreamWaitEvent(c->copy_in, c->ev_run[b], 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->tb_o[b].p, o_xyz + 3 * first, 3 * m * sizeof(float), hipMemcpyHostToDevice, c->copy_in);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->tb_d[b].p, d_xyz + 3 * first, 3 * m * sizeof(float), hipMemcpyHostToDevice, c->copy_in);
+    if (e == hipSuccess) e = hipEventRecord(c->ev_in[b], c->copy_in);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_in[b], 0);
+    if (e == hipSuccess && k >= 2) e = hipStreamWaitEvent(c->stream, c->ev_out[b], 0);
+    if (e != hipSuccess) break;
+    rc = rt_trace_batch_device(c, c->tb_o[b].p, c->tb_d[b].p, m, c->tb_id[b].p, c->tb_t[b].p, c->tb_n[b].p, 0);
+    if (rc != RT_OK) break;
+    e = hipEventRecord(c->ev_run[b], c->stream);
+    // copies from pageable memory hold the calling thread: the previous chunk's results go out while this chunk's kernel runs
+    if (e == hipSuccess && k >= 1) e = copy_out(k - 1);
   }
-  cleanup();
-  return rc;
+  if (e == hipSuccess && rc == RT_OK) e = copy_out(n_chunks - 1);
+  const hipError_t s0 = hipStreamSynchronize(c->copy_in), s1 = hipStreamSynchronize(c->stream), s2 = hipStreamSynchronize(c->copy_out);
+  if (rc != RT_OK) return rc;
+  if (e == hipSuccess) e = s0 != hipSuccess ? s0 : (s1 != hipSuccess ? s1 : s2);
+  if (e != hipSuccess) return fail(RT_ERR_DEVICE, "ray batch transfer: %s", hipGetErrorString(e));
+  return RT_OK;
 }
 
 int rt_synchronize(rt_ctx* c) {

@@ -114,3 +114,21 @@ def test_c4_cloud_tree_equals_scan_on_a_sample_of_rays(renderer):
     dist = np.linalg.norm(pnt - centre, axis=1)
     err = np.abs(dist - radius)
     assert np.median(err) < 1e-2 and np.quantile(err, 0.9) < 1e-1, (np.median(err), np.quantile(err, 0.9), err.max())
+
+
+def test_host_batch_in_chunks_equals_its_pieces(renderer):
+    """rt_trace_batch sends a large batch through the GPU in chunks with copies and kernels overlapped
+    (two buffer sets): the answers must be those of the same rays traced piece by piece."""
+    scene = rt.build_scene(rt.SCENE_CLOUD, n=60000, seed=3)
+    renderer.upload(scene, rt.ACCEL_LBVH)
+    n = (1 << 23) + (1 << 22) + 12345   # three full chunks and a short one
+    o, d = rt.gen_rays(77, 0, n)
+    ids, t, nrm = renderer.trace(o, d)
+    assert (ids >= 0).sum() > 1000
+    step = 3_000_000                      # below the chunk size: one chunk per call
+    for first in range(0, n, step):
+        sl = slice(first, min(n, first + step))
+        i2, t2, n2 = renderer.trace(o[sl], d[sl])
+        assert np.array_equal(ids[sl], i2)
+        assert np.array_equal(t[sl].view(np.uint32), t2.view(np.uint32))
+        assert np.array_equal(nrm[sl].view(np.uint32), n2.view(np.uint32))
