@@ -415,8 +415,8 @@ int split_fineness() {
 // The probe takes an eighth of the samples, between 8 and a cap: 32 when it runs in sweeps (counter RNG: short jobs
 // in tile order are about as efficient as the sorted main pass, and a longer probe measures costs better), 16 when
 // every pixel's probe is one job.  RT_PROBE_SAMPLES sets the length itself, for tuning (the split of a frame into probe
-// and main pass never changes the image).  Two-pass rendering needs at least 64 samples.
-constexpr int kMinTwoPassSamples = 64;
+// and main pass never changes the image).  Two-pass rendering needs at least 64 samples (16 with the reference's generator).
+constexpr int kMinTwoPassSamples = 64, kMinTwoPassSamplesSequential = 16;
 int probe_samples(int n_samples, bool swept) {
   static int cap = [] {
     const char* e = getenv("RT_PROBE_SAMPLES");
@@ -613,7 +613,10 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   // that order: the tail then consists of the cheapest pixels.
   const size_t n_rect = (size_t)tw * (size_t)th;
   const int n_samples = p->sample_end - p->sample_begin;
-  const bool two_pass = two_pass_enabled() && n_samples >= kMinTwoPassSamples && n_rect >= 16384;
+  // (with the counter RNG shorter frames are rendered in sweeps as a whole, see below; the reference's generator
+  // cannot start in the middle of a pixel, so there a probe pays from 16 samples on: 1080p x 32 spp 3 360 -> 4 340 Mpaths/s)
+  const int min_two_pass = p->rng_mode == RT_RNG_COUNTER ? kMinTwoPassSamples : kMinTwoPassSamplesSequential;
+  const bool two_pass = two_pass_enabled() && n_samples >= min_two_pass && n_rect >= 16384;
   HIP_TRY(hipEventRecord(c->ev_k0, c->stream));
   hipError_t e;
   // Few samples, counter RNG: the frame as a whole is rendered in sweeps (short jobs in tile order, per-sample
