@@ -70,6 +70,8 @@ def parse_args():
     ap.add_argument("--spheres", type=int)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    # "gloo" rehearses the N > 1 flow on a box with fewer GPUs than ranks (ranks then share devices); never a result
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     return ap.parse_args()
 
 
@@ -122,6 +124,9 @@ def cpu_baseline_trace(rt, scene, threads, seed):
 
 def main():
     args = parse_args()
+    if os.environ.get("RT_BENCH_WATCHDOG"):  # seconds after which every thread's stack is dumped and the process ends
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["RT_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -134,10 +139,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL
+        else:
+            dist.init_process_group("gloo")
 
     cfg = dict(CONFIGS[args.config])
     for k in ("width", "height", "spp"):
@@ -254,6 +264,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": result.pop("_scaling", "weak"), "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         })
+        if world > 1 and args.backend != "nccl":
+            result["rehearsal"] = f"{args.backend} backend, ranks sharing {torch.cuda.device_count()} GPU(s): not a measurement"
         traffic = measured_traffic(kname, result["config"]["workload"])
         if args.config == "c4":
             result["roofline"] = {"bound": "hbm", "achieved": algo_bytes / (avg_kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
