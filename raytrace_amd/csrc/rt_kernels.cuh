@@ -207,7 +207,7 @@ struct searcher {
     ts.c.redo = true;  // finish() runs the scan
     return false;
   }
-  static constexpr bool leaf_steps = T::tree && !T::lds;  // leaves wait for a step of their own
+  static constexpr bool leaf_steps = T::tree && (!T::lds || RT_LDS_LEAF_STEPS);  // leaves wait for a step of their own
   RT_DEV bool node_ready() const { return T::tree && ts.node_ready(); }
   RT_DEV bool has_leaf() const { return T::tree && ts.has_leaf(); }
   RT_DEV bool active() const { return T::tree && ts.active(); }

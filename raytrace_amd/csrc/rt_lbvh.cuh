@@ -256,9 +256,9 @@ __global__ __launch_bounds__(256) void lbvh_collapse_kernel(const float4* leaf_s
       }
       nd.lox[s] = b.lo[0]; nd.loy[s] = b.lo[1]; nd.loz[s] = b.lo[2];
       nd.hix[s] = b.hi[0]; nd.hiy[s] = b.hi[1]; nd.hiz[s] = b.hi[2];
-    } else {  // unused slot: a far-away point box, and a reference no test accepts
-      nd.lox[s] = nd.loy[s] = nd.loz[s] = 3.0e38f;
-      nd.hix[s] = nd.hiy[s] = nd.hiz[s] = 3.0e38f;
+    } else {  // unused slot: an inverted box no ray enters (tree_search::step_node), and a reference no test accepts
+      nd.lox[s] = nd.loy[s] = nd.loz[s] = __builtin_inff();
+      nd.hix[s] = nd.hiy[s] = nd.hiz[s] = -__builtin_inff();
       nd.ref[s] = RT_REF_EMPTY;
     }
   }

@@ -347,6 +347,9 @@ RT_DEV void child_interval(float lx, float ly, float lz, float hx, float hy, flo
 // and cost more in occupancy than it saves in look-ups).  Every lane of the wave must call this
 // (my_node < 0: nothing wanted); returns where the staged part of the lane's node lies.
 // The staging area and the returned place are byte offsets into the kernel's dynamic LDS.
+#ifndef RT_LDS_LEAF_STEPS
+#define RT_LDS_LEAF_STEPS 0   // 1: trees in LDS queue their leaves for voted leaf steps too (tuning builds)
+#endif
 #ifndef RT_STAGE_PIECES
 #define RT_STAGE_PIECES 4
 #endif
@@ -473,7 +476,7 @@ struct tree_search {
   slab_consts sl;
   trav_candidate c;
   int cur, sp;  // cur: node to test next, -1 when the stack has run dry
-  static constexpr bool LEAF_INLINE = PACKED;
+  static constexpr bool LEAF_INLINE = PACKED && !RT_LDS_LEAF_STEPS;
   static constexpr bool SELECT = PAD_RAY && PACKED;  // planes picked by direction sign (slab_consts)
   leaf_queue<PACKED> lq;
 
@@ -505,6 +508,15 @@ struct tree_search {
     sl.inv_d = mk3(__builtin_amdgcn_rcpf(slab_dir(d.x)), __builtin_amdgcn_rcpf(slab_dir(d.y)),
                    __builtin_amdgcn_rcpf(slab_dir(d.z)));
     if (PAD_RAY) make_slab_consts<SELECT>(sc, o, sl.inv_d, a, c, sl);
+    if (SELECT) {
+      // the inverted boxes of unused slots stay inverted only under finite slab constants (an origin some 1e18
+      // away along a nearly flat direction overflows them): the scan decides such a ray
+      const float sum = ((fabsf(sl.k_lo.x) + fabsf(sl.k_lo.y)) + fabsf(sl.k_lo.z)) + ((fabsf(sl.k_hi.x) + fabsf(sl.k_hi.y)) + fabsf(sl.k_hi.z));
+      if (!(sum < __builtin_inff())) {
+        c.redo = true;
+        return false;
+      }
+    }
     if (sc.root < 0) {  // a single sphere in the tree
       consider_sphere<COUNTED>(sv.leaf_sph[~sc.root], sv.leaf_idx[~sc.root], o, d, a, c, k);
       return false;
@@ -563,10 +575,13 @@ struct tree_search {
     unsigned leaf_mask = 0;
 #pragma unroll
     for (int ch = 0; ch < 4; ch++) {
-      ok[ch] = tn[ch] <= tf[ch] && refs[ch] != RT_REF_EMPTY;
+      // (an unused slot holds an inverted box, lo = +inf and hi = -inf: the entry plane picked by the direction's sign
+      // then gives tn = +inf and the exit plane tf = -inf on every axis, so the test by selected planes needs no look at
+      // the reference; min / max of the two parameters would undo the inversion)
+      ok[ch] = SELECT ? tn[ch] <= tf[ch] : bool((tn[ch] <= tf[ch]) & (refs[ch] != RT_REF_EMPTY));
       RT_COUNT(k, node_tests, refs[ch] != RT_REF_EMPTY ? 1u : 0u);
       if (LEAF_INLINE) {
-        leaf_mask |= (ok[ch] ? ((uint32_t)refs[ch] >> 31) : 0u) << ch;  // arithmetic, not a branch per child
+        leaf_mask |= ((ok[ch] ? 1u : 0u) & ((uint32_t)refs[ch] >> 31)) << ch;  // arithmetic, not a branch per child
       } else if (ok[ch] && refs[ch] < 0) {
         lq.push(~refs[ch]);
       }
@@ -578,7 +593,10 @@ struct tree_search {
     while (LEAF_INLINE && leaf_mask) {
       const int ch = __builtin_ctz(leaf_mask);
       leaf_mask &= leaf_mask - 1;
-      const int r = ch == 0 ? refs[0] : ch == 1 ? refs[1] : ch == 2 ? refs[2] : refs[3];
+      int r = refs[0];  // three selects, not a branch per child
+      r = ch == 1 ? refs[1] : r;
+      r = ch == 2 ? refs[2] : r;
+      r = ch == 3 ? refs[3] : r;
       const int pos = ~r;
       consider_sphere<COUNTED>(sv.leaf_sph[pos], sv.leaf_idx[pos], o, d, a, c, k);
     }
