@@ -305,6 +305,204 @@ int build_lbvh(rt_ctx* c) {
   return RT_OK;
 }
 
+// ---- hierarchy of a small scene, built on the host ---------------------------
+// A scene whose tree fits LDS has at most a few thousand spheres: a top-down build by the surface
+// area heuristic (every split position along the three axes is priced, a leaf holds one sphere)
+// takes a millisecond or two on one core and gives the render kernels fewer nodes to visit than
+// the Morton-order tree.  The binary tree is collapsed into 4-wide nodes by opening, among the
+// children gathered so far, the one with the largest surface until there are four.  Boxes are the
+// same centre -+ |r| boxes the device build makes, so the traversal's box-growing rules apply as
+// they are.  RT_BUILDER=lbvh keeps the device build for every scene.
+constexpr int kSahMaxLeaves = 2048;
+constexpr int kSahMaxWideDepth = 20;
+
+struct sah_bin_node {
+  float lo[3], hi[3], rmin;
+  int left, right;  // children, or -1 / sphere (index into the tree arrays) for a leaf
+};
+
+struct sah_builder {
+  const std::vector<float4>& sph;
+  const std::vector<float>& radius;
+  std::vector<sah_bin_node> bin;
+  std::vector<int> order;          // spheres of the range being split
+  std::vector<float> area_right;   // sweep scratch
+  // outputs
+  std::vector<bvh4_node> nodes;
+  std::vector<int> leaf_order;     // leaf position -> index into the tree arrays
+  int wide_depth = 0;
+
+  sah_builder(const std::vector<float4>& s, const std::vector<float>& r) : sph(s), radius(r) {}
+
+  static float half_area(const float* lo, const float* hi) {
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+  }
+  void leaf_box(int i, float* lo, float* hi) const {
+    const float r = std::fabs(radius[i]);
+    const float c[3] = {sph[i].x, sph[i].y, sph[i].z};
+    for (int a = 0; a < 3; a++) {
+      lo[a] = c[a] - r;
+      hi[a] = c[a] + r;
+    }
+  }
+  static void grow(float* lo, float* hi, const float* l2, const float* h2) {
+    for (int a = 0; a < 3; a++) {
+      lo[a] = std::fmin(lo[a], l2[a]);
+      hi[a] = std::fmax(hi[a], h2[a]);
+    }
+  }
+  float centre(int i, int axis) const { return axis == 0 ? sph[i].x : axis == 1 ? sph[i].y : sph[i].z; }
+
+  // Builds the subtree over order[b, e) and returns its node.
+  int build(int b, int e) {
+    const int id = (int)bin.size();
+    bin.push_back(sah_bin_node());
+    if (e - b == 1) {
+      sah_bin_node& n = bin[id];
+      leaf_box(order[b], n.lo, n.hi);
+      n.rmin = std::fabs(radius[order[b]]);
+      n.left = -1;
+      n.right = order[b];
+      return id;
+    }
+    float best_cost = 0.0f;
+    int best_axis = -1, best_split = -1;
+    std::vector<int> sorted(order.begin() + b, order.begin() + e), best_sorted;
+    const int m = e - b;
+    for (int axis = 0; axis < 3; axis++) {
+      std::stable_sort(sorted.begin(), sorted.end(), [&](int x, int y) { return centre(x, axis) < centre(y, axis); });
+      float lo[3], hi[3], l2[3], h2[3];
+      leaf_box(sorted[m - 1], lo, hi);
+      area_right[m - 1] = half_area(lo, hi);
+      for (int i = m - 2; i >= 1; i--) {
+        leaf_box(sorted[i], l2, h2);
+        grow(lo, hi, l2, h2);
+        area_right[i] = half_area(lo, hi);
+      }
+      leaf_box(sorted[0], lo, hi);
+      for (int i = 1; i < m; i++) {  // the left part holds sorted[0, i)
+        const float cost = half_area(lo, hi) * (float)i + area_right[i] * (float)(m - i);
+        if (best_axis < 0 || cost < best_cost) {
+          best_cost = cost;
+          best_axis = axis;
+          best_split = i;
+        }
+        leaf_box(sorted[i], l2, h2);
+        grow(lo, hi, l2, h2);
+      }
+      if (best_axis == axis) best_sorted = sorted;
+    }
+    std::copy(best_sorted.begin(), best_sorted.end(), order.begin() + b);
+    const int l = build(b, b + best_split);
+    const int r = build(b + best_split, e);
+    sah_bin_node& n = bin[id];
+    for (int a = 0; a < 3; a++) {
+      n.lo[a] = std::fmin(bin[l].lo[a], bin[r].lo[a]);
+      n.hi[a] = std::fmax(bin[l].hi[a], bin[r].hi[a]);
+    }
+    n.rmin = std::fmin(bin[l].rmin, bin[r].rmin);
+    n.left = l;
+    n.right = r;
+    return id;
+  }
+
+  // The 4-wide node of binary node `id` (not a leaf); returns its slot.
+  int emit(int id, int level) {
+    wide_depth = std::max(wide_depth, level);
+    int kids[4] = {bin[id].left, bin[id].right, -1, -1};
+    int nk = 2;
+    while (nk < 4) {
+      int pick = -1;
+      float pick_area = -1.0f;
+      for (int s = 0; s < nk; s++) {
+        const sah_bin_node& k = bin[kids[s]];
+        if (k.left >= 0 && half_area(k.lo, k.hi) > pick_area) {
+          pick = s;
+          pick_area = half_area(k.lo, k.hi);
+        }
+      }
+      if (pick < 0) break;
+      const int opened = kids[pick];
+      for (int s = nk; s > pick + 1; s--) kids[s] = kids[s - 1];  // the two children take the opened one's place
+      kids[pick] = bin[opened].left;
+      kids[pick + 1] = bin[opened].right;
+      nk++;
+    }
+    const int slot = (int)nodes.size();
+    nodes.push_back(bvh4_node());
+    bvh4_node nd;
+    for (int s = 0; s < 4; s++) {
+      if (s < nk) {
+        const sah_bin_node& k = bin[kids[s]];
+        nd.lox[s] = k.lo[0]; nd.loy[s] = k.lo[1]; nd.loz[s] = k.lo[2];
+        nd.hix[s] = k.hi[0]; nd.hiy[s] = k.hi[1]; nd.hiz[s] = k.hi[2];
+        nd.rmin[s] = k.rmin;
+        if (k.left < 0) {
+          nd.ref[s] = ~(int32_t)leaf_order.size();
+          leaf_order.push_back(k.right);
+        } else {
+          nd.ref[s] = emit(kids[s], level + 1);
+        }
+      } else {  // unused slot: the inverted box of the device build (lbvh_collapse_kernel)
+        nd.lox[s] = nd.loy[s] = nd.loz[s] = __builtin_inff();
+        nd.hix[s] = nd.hiy[s] = nd.hiz[s] = -__builtin_inff();
+        nd.rmin[s] = 0.0f;
+        nd.ref[s] = RT_REF_EMPTY;
+      }
+    }
+    nodes[slot] = nd;
+    return slot;
+  }
+};
+
+bool host_builder_enabled() {  // read at every upload, so that one process can compare the two builds
+  const char* e = getenv("RT_BUILDER");
+  return !(e && std::strcmp(e, "lbvh") == 0);
+}
+
+// Host build for a tree of 2 .. kSahMaxLeaves spheres with finite centres and radii.  Fills what
+// build_lbvh fills.
+int build_sah_host(rt_ctx* c, const std::vector<float4>& tree_sph, const std::vector<float>& tree_r,
+                   const std::vector<int32_t>& tree_orig) {
+  const int n = (int)tree_sph.size();
+  HIP_TRY(hipEventRecord(c->ev_b0, c->stream));
+  sah_builder b(tree_sph, tree_r);
+  b.bin.reserve(2 * (size_t)n);
+  b.order.resize((size_t)n);
+  b.area_right.resize((size_t)n);
+  for (int i = 0; i < n; i++) b.order[i] = i;
+  const int root = b.build(0, n);
+  b.nodes.reserve((size_t)n);
+  b.emit(root, 1);
+  std::vector<float4> leaf_sph((size_t)n);
+  std::vector<float> leaf_r((size_t)n);
+  std::vector<int32_t> leaf_idx((size_t)n);
+  for (int pos = 0; pos < n; pos++) {
+    const int i = b.leaf_order[pos];
+    leaf_sph[pos] = tree_sph[i];
+    leaf_r[pos] = tree_r[i];
+    leaf_idx[pos] = tree_orig[i];
+  }
+  HIP_TRY(c->leaf_sph.upload(leaf_sph, c->stream));
+  HIP_TRY(c->leaf_r.upload(leaf_r, c->stream));
+  HIP_TRY(c->leaf_idx.upload(leaf_idx, c->stream));
+  HIP_TRY(c->nodes.upload(b.nodes, c->stream));
+  HIP_TRY(hipEventRecord(c->ev_b1, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the host vectors go out of scope
+  c->n_nodes = (int)b.nodes.size();
+  c->root = 0;
+  c->depth = 2 * b.wide_depth;  // attach_overflow and rt_lbvh_depth count binary levels
+  c->abs_max = 0.0f;
+  for (int a = 0; a < 3; a++) {
+    c->root_lo[a] = b.bin[root].lo[a];
+    c->root_hi[a] = b.bin[root].hi[a];
+    c->abs_max += std::fmax(std::fabs(c->root_lo[a]), std::fabs(c->root_hi[a]));
+  }
+  c->have_build_time = true;
+  return RT_OK;
+}
+
 // Which search the kernels use for the uploaded scene.
 scene_counts counts_of(const rt_ctx* c) {
   scene_counts n;
@@ -930,8 +1128,25 @@ int rt_scene_upload(rt_ctx* c, const void* spheres_std140, int n_spheres, const 
   c->depth = 0;
   c->have_build_time = false;
   if (accel == RT_ACCEL_LBVH && c->n_leaf > 0) {
-    rc = build_lbvh(c);
-    if (rc) return rc;
+    bool built = false;
+    if (host_builder_enabled() && c->n_leaf >= 2 && c->n_leaf <= kSahMaxLeaves) {
+      bool finite = true;
+      for (size_t i = 0; i < tree_sph.size(); i++)
+        finite = finite && std::isfinite(tree_sph[i].x) && std::isfinite(tree_sph[i].y) && std::isfinite(tree_sph[i].z) &&
+                 std::isfinite(tree_r[i]);
+      if (finite) {
+        rc = build_sah_host(c, tree_sph, tree_r, tree_orig);
+        if (rc) return rc;
+        const int search = choose_search(c);  // kept only when the render kernels can hold it in LDS
+        // (and when it is not degenerate: a chain as deep as coincident centres can make would overflow the
+        // traversal stacks kept in LDS and send its rays to the scan)
+        built = (search == SEARCH_TREE_LDS_RAY || search == SEARCH_TREE_LDS_NODE) && c->depth <= 2 * kSahMaxWideDepth;
+      }
+    }
+    if (!built) {
+      rc = build_lbvh(c);
+      if (rc) return rc;
+    }
   }
   c->search = choose_search(c);
   c->have_scene = true;

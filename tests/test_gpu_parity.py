@@ -316,3 +316,49 @@ def test_few_samples_in_sweeps_match_oracle(renderer, accel):
     # the CPU restatement adds the eight samples in order in one go: the same sum
     acc, _ = oracle.render(scene, rt.make_params(cam, 160, 104, 8, rng_mode=rt.RNG_COUNTER), threads=8)
     assert_same_f32(lin, oracle.resolve(acc, 8)[0], "linear radiance")
+
+
+def test_host_and_device_hierarchy_builds_agree(renderer, monkeypatch):
+    """A tree small enough for LDS is built on the host (surface area heuristic) unless RT_BUILDER=lbvh keeps the
+    device's Morton-order build: both trees, and a cloud with coincident and nested spheres, must give the scan's
+    answers bit for bit — frames and closest-hit batches."""
+    scene = rt.build_scene(rt.SCENE_RANDOM_SPHERES)
+    cam = rt.scene_camera(rt.SCENE_RANDOM_SPHERES)
+    p = rt.make_params(cam, 160, 90, 4, rng_mode=rt.RNG_COUNTER)
+    frames, steps = {}, {}
+    for builder in ("sah", "lbvh"):
+        monkeypatch.setenv("RT_BUILDER", builder)
+        renderer.upload(scene, rt.ACCEL_LBVH)
+        renderer.clear()
+        renderer.render(p, counted=True)
+        frames[builder] = renderer.readback(rgb8=False)[0]
+        steps[builder] = renderer.counters()["node_tests"]
+        assert renderer.last_kernel_ms()[1] == "rt_render_kernel<lbvh4,lds,pad_ray>"
+    assert_same_f32(frames["sah"], frames["lbvh"], "host-built tree vs device-built tree")
+    assert steps["sah"] < steps["lbvh"]  # what the host build is for
+    acc, _ = oracle.render(scene, p, threads=8)
+    assert_same_f32(frames["sah"], oracle.resolve(acc, 4)[0], "host-built tree vs CPU restatement")
+
+    # duplicates, concentric spheres and a line of touching ones: split positions with equal cost, zero-extent boxes
+    rng = np.random.default_rng(7)
+    centres = np.concatenate([np.zeros((40, 3)), np.repeat(rng.uniform(-5, 5, (30, 3)), 3, axis=0),
+                              np.stack([np.arange(60) * 0.5, np.zeros(60), np.zeros(60)], axis=1)]).astype(np.float32)
+    radii = np.concatenate([np.linspace(0.1, 2.0, 40), np.tile([0.2, 0.4, 0.8], 30), np.full(60, 0.25)]).astype(np.float32)
+    rec = np.zeros((len(radii), 32), dtype=np.uint8)
+    rec[:, 4:8] = radii.view(np.uint8).reshape(-1, 4)
+    rec[:, 16:28] = centres.view(np.uint8).reshape(-1, 12)
+    odd = rt.Scene(rec.tobytes(), scene.materials)
+    o = rng.uniform(-8, 8, (20000, 3)).astype(np.float32)
+    d = rng.normal(size=(20000, 3)).astype(np.float32)
+    o[:200] = centres[rng.integers(0, len(centres), 200)]  # rays that start at centres
+    monkeypatch.delenv("RT_BUILDER")
+    renderer.upload(odd, rt.ACCEL_LINEAR)
+    want = renderer.trace(o, d)
+    for builder in ("sah", "lbvh"):
+        monkeypatch.setenv("RT_BUILDER", builder)
+        renderer.upload(odd, rt.ACCEL_LBVH)
+        got = renderer.trace(o, d)
+        assert np.array_equal(got[0], want[0]), builder
+        assert_same_f32(got[1], want[1], f"t ({builder})")
+        assert_same_f32(got[2], want[2], f"normal ({builder})")
+    assert (want[0] >= 0).sum() > 2000
