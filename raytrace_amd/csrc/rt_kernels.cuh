@@ -463,9 +463,10 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
             if (A.pass == 3) {  // sweep q takes the q-th part of every pixel's probe samples
               const uint32_t sweep = item / tile_items;
               it = item - sweep * tile_items;
-              const int n_probe = P.sample_end - P.sample_begin;
-              job.y = (uint32_t)(P.sample_begin + (int)(((long long)n_probe * sweep) / A.sweeps));
-              job.z = (uint32_t)(P.sample_begin + (int)(((long long)n_probe * (sweep + 1)) / A.sweeps));
+              // (32-bit arithmetic: the host runs a pass in sweeps only over fewer than 2^24 samples, in at most 64 sweeps)
+              const uint32_t n_probe = (uint32_t)(P.sample_end - P.sample_begin), first = n_probe * sweep / (uint32_t)A.sweeps;
+              job.y = (uint32_t)P.sample_begin + first;
+              job.z = (uint32_t)P.sample_begin + (n_probe * sweep + n_probe) / (uint32_t)A.sweeps;
             }
             const uint32_t tile = it >> 6, within = it & 63u;
             x = P.tile_x0 + (int)(tile % (uint32_t)tiles_x) * 8 + (int)(within & 7u);
