@@ -309,8 +309,8 @@ int build_lbvh(rt_ctx* c) {
 // A scene whose tree fits LDS has at most a few thousand spheres: a top-down build by the surface
 // area heuristic (every split position along the three axes is priced, a leaf holds one sphere)
 // takes a millisecond or two on one core and gives the render kernels fewer nodes to visit than
-// the Morton-order tree.  The binary tree is collapsed into 4-wide nodes by opening, among the
-// children gathered so far, the one with the largest surface until there are four.  Boxes are the
+// the Morton-order tree.  The binary tree is collapsed into 4-wide nodes along the cuts that make
+// the summed surface of the 4-wide nodes smallest (sah_builder::plan_collapse).  Boxes are the
 // same centre -+ |r| boxes the device build makes, so the traversal's box-growing rules apply as
 // they are.  RT_BUILDER=lbvh keeps the device build for every scene.
 constexpr int kSahMaxLeaves = 2048;
@@ -407,28 +407,65 @@ struct sah_builder {
     return id;
   }
 
+  // Which binary nodes become the children of a 4-wide node: the cut that makes the summed surface of all
+  // 4-wide nodes below smallest (a ray visits a node with a probability proportional to its surface, and a
+  // visit costs the same whether two or four slots are in use).  slots[n][k] = smallest sum for the subtree
+  // of n handed k slots of its parent: either n itself takes one slot and becomes a node (its surface plus
+  // its own best cut into four), or its two children share the k slots; a leaf costs nothing.
+  std::vector<float> slots;   // 4 per binary node, k = 1 .. 4
+  std::vector<unsigned char> cut;  // slots given to the left child, 0 = n takes one slot itself
+  void plan_collapse() {
+    slots.assign(4 * bin.size(), 0.0f);
+    cut.assign(4 * bin.size(), 0);
+    for (int n = (int)bin.size() - 1; n >= 0; n--) {  // children were created after their parents
+      if (bin[n].left < 0) continue;
+      const int l = bin[n].left, r = bin[n].right;
+      auto shared = [&](int k, int& best_i) {  // the children of n share k >= 2 slots
+        float best = 0.0f;
+        best_i = 0;
+        for (int i = 1; i < k; i++) {
+          const float v = slots[4 * l + i - 1] + slots[4 * r + k - i - 1];
+          if (best_i == 0 || v < best) {
+            best = v;
+            best_i = i;
+          }
+        }
+        return best;
+      };
+      int i4;
+      const float own = half_area(bin[n].lo, bin[n].hi) + shared(4, i4);  // n as a node of its own
+      slots[4 * n] = own;
+      for (int k = 2; k <= 4; k++) {
+        int i;
+        const float v = shared(k, i);
+        if (v < own) {
+          slots[4 * n + k - 1] = v;
+          cut[4 * n + k - 1] = (unsigned char)i;
+        } else {
+          slots[4 * n + k - 1] = own;
+        }
+      }
+      cut[4 * n] = (unsigned char)i4;  // for k = 1 the entry holds the node's own cut into four
+    }
+  }
+  void gather(int n, int k, int* kids, int& nk) const {
+    if (bin[n].left < 0 || k == 1 || cut[4 * n + k - 1] == 0) {
+      kids[nk++] = n;
+      return;
+    }
+    const int i = cut[4 * n + k - 1];
+    gather(bin[n].left, i, kids, nk);
+    gather(bin[n].right, k - i, kids, nk);
+  }
+
   // The 4-wide node of binary node `id` (not a leaf); returns its slot.
   int emit(int id, int level) {
     wide_depth = std::max(wide_depth, level);
-    int kids[4] = {bin[id].left, bin[id].right, -1, -1};
-    int nk = 2;
-    while (nk < 4) {
-      int pick = -1;
-      float pick_area = -1.0f;
-      for (int s = 0; s < nk; s++) {
-        const sah_bin_node& k = bin[kids[s]];
-        if (k.left >= 0 && half_area(k.lo, k.hi) > pick_area) {
-          pick = s;
-          pick_area = half_area(k.lo, k.hi);
-        }
-      }
-      if (pick < 0) break;
-      const int opened = kids[pick];
-      for (int s = nk; s > pick + 1; s--) kids[s] = kids[s - 1];  // the two children take the opened one's place
-      kids[pick] = bin[opened].left;
-      kids[pick + 1] = bin[opened].right;
-      nk++;
-    }
+    int kids[4] = {-1, -1, -1, -1};
+    int nk = 0;
+    const int i4 = cut[4 * id];
+    gather(bin[id].left, i4, kids, nk);
+    gather(bin[id].right, 4 - i4, kids, nk);
     const int slot = (int)nodes.size();
     nodes.push_back(bvh4_node());
     bvh4_node nd;
@@ -474,6 +511,7 @@ int build_sah_host(rt_ctx* c, const std::vector<float4>& tree_sph, const std::ve
   for (int i = 0; i < n; i++) b.order[i] = i;
   const int root = b.build(0, n);
   b.nodes.reserve((size_t)n);
+  b.plan_collapse();
   b.emit(root, 1);
   std::vector<float4> leaf_sph((size_t)n);
   std::vector<float> leaf_r((size_t)n);
