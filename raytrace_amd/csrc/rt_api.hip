@@ -383,7 +383,8 @@ struct sah_builder {
       leaf_box(sorted[0], lo, hi);
       for (int i = 1; i < m; i++) {  // the left part holds sorted[0, i)
         const float cost = half_area(lo, hi) * (float)i + area_right[i] * (float)(m - i);
-        if (best_axis < 0 || cost < best_cost) {
+        // (equal costs — coincident spheres — go to the split nearest the middle: a chain would be rejected later)
+        if (best_axis < 0 || cost < best_cost || (cost == best_cost && std::abs(2 * i - m) < std::abs(2 * best_split - m))) {
           best_cost = cost;
           best_axis = axis;
           best_split = i;

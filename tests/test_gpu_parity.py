@@ -342,8 +342,10 @@ def test_host_and_device_hierarchy_builds_agree(renderer, monkeypatch):
     # duplicates, concentric spheres and a line of touching ones: split positions with equal cost, zero-extent boxes
     rng = np.random.default_rng(7)
     centres = np.concatenate([np.zeros((40, 3)), np.repeat(rng.uniform(-5, 5, (30, 3)), 3, axis=0),
-                              np.stack([np.arange(60) * 0.5, np.zeros(60), np.zeros(60)], axis=1)]).astype(np.float32)
-    radii = np.concatenate([np.linspace(0.1, 2.0, 40), np.tile([0.2, 0.4, 0.8], 30), np.full(60, 0.25)]).astype(np.float32)
+                              np.stack([np.arange(60) * 0.5, np.zeros(60), np.zeros(60)], axis=1),
+                              np.full((300, 3), 3.0)]).astype(np.float32)
+    radii = np.concatenate([np.linspace(0.1, 2.0, 40), np.tile([0.2, 0.4, 0.8], 30), np.full(60, 0.25),
+                            np.full(300, 0.3)]).astype(np.float32)  # the last 300 are one sphere 300 times: ties go to the first
     rec = np.zeros((len(radii), 32), dtype=np.uint8)
     rec[:, 4:8] = radii.view(np.uint8).reshape(-1, 4)
     rec[:, 16:28] = centres.view(np.uint8).reshape(-1, 12)
