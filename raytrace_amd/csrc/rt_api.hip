@@ -626,6 +626,24 @@ int split_rows() {
   return v;
 }
 
+// Fewest jobs a pixel that may be cut is cut into (RT_MIN_PARTS), and the bytes its per-sample radiance may take
+// (RT_SPLIT_BUDGET_MB).
+int min_parts() {
+  static int v = [] {
+    const char* e = getenv("RT_MIN_PARTS");
+    const int x = e ? atoi(e) : 1;
+    return x < 1 ? 1 : (x > 64 ? 64 : x);
+  }();
+  return v;
+}
+size_t split_budget_bytes() {
+  static size_t v = [] {
+    const char* e = getenv("RT_SPLIT_BUDGET_MB");
+    return e && atoll(e) > 0 ? (size_t)atoll(e) << 20 : kSplitBudgetBytes;
+  }();
+  return v;
+}
+
 // Sweeps of the probe pass (RT_PROBE_SWEEPS overrides, 1 = unsplit probe).
 int probe_sweeps() {
   static int v = [] {
@@ -935,7 +953,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       const uint32_t n = (uint32_t)n_rect;
       // a job should be a small fraction (1 / split_fineness()) of a lane's fair share of the frame
       const uint32_t lanes = (uint32_t)c->n_cu * 1024u * (uint32_t)split_fineness();
-      size_t want = kSplitBudgetBytes / ((size_t)main_samples * 3 * sizeof(float));
+      size_t want = split_budget_bytes() / ((size_t)main_samples * 3 * sizeof(float));
       // frames with fewer than four pixels per lane balance only if most pixels may be cut (measured: 960x540
       // +15 %); larger frames need the most expensive pixels only, and more rows just add traffic
       const size_t row_cap = split_rows() >= 0 ? (size_t)split_rows() : (n_rect < (size_t)c->n_cu * 4096 ? n_rect : (size_t)65536);
@@ -945,7 +963,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       HIP_TRY(c->plan_first.resize(n));
       HIP_TRY(c->plan_counts.resize(1));
       HIP_TRY(c->plan_total.resize(1));
-      HIP_TRY(c->plan_jobs.resize((size_t)n + (size_t)lanes + 64));
+      HIP_TRY(c->plan_jobs.resize((size_t)n * (size_t)min_parts() + (size_t)lanes + 64));
       if (splittable) HIP_TRY(c->split_samples.resize((size_t)max_split * (size_t)main_samples * 3));
       size_t scan_bytes = 0;
       HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, c->plan_parts.p, c->plan_first.p, 0u, n, rocprim::plus<uint32_t>(), c->stream));
@@ -954,7 +972,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       const unsigned grid = (n + 255) / 256;
       rt_plan_cost_kernel<<<grid < 1024 ? grid : 1024, 256, 0, c->stream>>>(c->carry_cost.p, n, c->plan_total.p);
       rt_plan_count_kernel<<<grid, 256, 0, c->stream>>>(c->carry_cost.p, c->order_idx.p, n, c->plan_total.p, lanes, max_split, main_samples,
-                                                       splittable, c->plan_parts.p);
+                                                       splittable, (uint32_t)min_parts(), c->plan_parts.p);
       HIP_TRY(hipGetLastError());
       HIP_TRY(rocprim::exclusive_scan(c->scan_temp.p, scan_bytes, c->plan_parts.p, c->plan_first.p, 0u, n, rocprim::plus<uint32_t>(),
                                       c->stream));

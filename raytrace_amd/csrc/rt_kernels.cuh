@@ -566,11 +566,11 @@ __global__ __launch_bounds__(256) void rt_plan_cost_kernel(const uint32_t* cost,
 // fraction of a lane's fair share; at least 8 samples each, at most 64 parts, only the first
 // max_split positions (the most expensive pixels) and only when splittable.
 RT_DEV uint32_t plan_parts(unsigned long long cost, unsigned long long total, uint32_t lanes, uint32_t i, uint32_t max_split,
-                           int samples, int splittable) {
+                           int samples, int splittable, uint32_t min_parts) {
   if (!splittable || i >= max_split || total == 0ull) return 1u;
   unsigned long long parts = (cost * lanes + total - 1ull) / total;
   const unsigned long long most = (unsigned long long)max(samples / 8, 1);
-  parts = parts < 1ull ? 1ull : parts;
+  parts = parts < (unsigned long long)min_parts ? (unsigned long long)min_parts : parts;
   parts = parts > 64ull ? 64ull : parts;
   parts = parts > most ? most : parts;
   return (uint32_t)parts;
@@ -578,9 +578,9 @@ RT_DEV uint32_t plan_parts(unsigned long long cost, unsigned long long total, ui
 
 __global__ __launch_bounds__(256) void rt_plan_count_kernel(const uint32_t* cost, const uint32_t* order, uint32_t n,
                                                            const unsigned long long* total, uint32_t lanes, uint32_t max_split,
-                                                           int samples, int splittable, uint32_t* parts) {
+                                                           int samples, int splittable, uint32_t min_parts, uint32_t* parts) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) parts[i] = plan_parts(cost[order[i]], *total, lanes, i, max_split, samples, splittable);
+  if (i < n) parts[i] = plan_parts(cost[order[i]], *total, lanes, i, max_split, samples, splittable, min_parts);
 }
 
 // first[i] = exclusive prefix sum of parts.  Writes the jobs of pixel i and, from the last pixel, the job count.
