@@ -67,7 +67,7 @@ struct dev_buf {
 };
 
 // Memory for the per-sample radiance of pixels whose main pass is cut into several jobs.
-constexpr size_t kSplitBudgetBytes = (size_t)2 << 30;
+constexpr size_t kSplitBudgetBytes = (size_t)32 << 30;
 // The same for the probe pass in sweeps (every pixel's probe samples): beyond this the probe runs unsplit.
 constexpr size_t kProbeBudgetBytes = (size_t)4 << 30;
 // Largest dynamic LDS a launch may ask for (the CU has 160 KiB).
@@ -626,16 +626,23 @@ int split_rows() {
   return v;
 }
 
-// Fewest jobs a pixel that may be cut is cut into (RT_MIN_PARTS), and the bytes its per-sample radiance may take
-// (RT_SPLIT_BUDGET_MB).
-int min_parts() {
-  static int v = [] {
+// Fewest jobs a pixel that may be cut is cut into.  The jobs of a pixel are neighbours in the main pass's order, so a
+// wave that holds k jobs each of 64 / k pixels follows rays through a k times smaller part of the image than one
+// that holds 64 pixels — what a frame of k times the pixels gets for nothing (measured: the same scene runs 14 %
+// faster per path at 3840x2160 than at 1920x1080 with one job per pixel).  Chosen so that a lane sees about 48 jobs:
+// 6 at 1920x1080 (main pass 61.8 -> 54 ms), 3 at 2560x1440, 1 from about 3500x2000 on (there more jobs only add
+// traffic); RT_MIN_PARTS overrides.
+int min_parts(size_t n_rect, size_t lanes) {
+  static int forced = [] {
     const char* e = getenv("RT_MIN_PARTS");
-    const int x = e ? atoi(e) : 1;
-    return x < 1 ? 1 : (x > 64 ? 64 : x);
+    const int x = e ? atoi(e) : 0;
+    return x < 0 ? 0 : (x > 64 ? 64 : x);
   }();
-  return v;
+  if (forced > 0) return forced;
+  const size_t k = 48 * lanes / (n_rect > 0 ? n_rect : 1);
+  return (int)(k < 1 ? 1 : (k > 8 ? 8 : k));
 }
+// Bytes the per-sample radiance of cut pixels may take (RT_SPLIT_BUDGET_MB overrides kSplitBudgetBytes).
 size_t split_budget_bytes() {
   static size_t v = [] {
     const char* e = getenv("RT_SPLIT_BUDGET_MB");
@@ -859,6 +866,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   a.n_jobs = nullptr;
   a.split_samples = nullptr;
   a.main_samples = 0;
+  a.split_rows = 0;
   a.carry_colour = nullptr;
   a.carry_rng = a.carry_cost = nullptr;
   // A pixel is the unit of work (its sum must be formed in sample order), so
@@ -954,16 +962,26 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       // a job should be a small fraction (1 / split_fineness()) of a lane's fair share of the frame
       const uint32_t lanes = (uint32_t)c->n_cu * 1024u * (uint32_t)split_fineness();
       size_t want = split_budget_bytes() / ((size_t)main_samples * 3 * sizeof(float));
-      // frames with fewer than four pixels per lane balance only if most pixels may be cut (measured: 960x540
-      // +15 %); larger frames need the most expensive pixels only, and more rows just add traffic
-      const size_t row_cap = split_rows() >= 0 ? (size_t)split_rows() : (n_rect < (size_t)c->n_cu * 4096 ? n_rect : (size_t)65536);
+      // (only where rays walk a tree worth the name: the scan and a tree of a few spheres gain nothing from
+      // neighbouring rays, and every sample stored and read back costs them 24 bytes of traffic — the two-sphere
+      // noise scene ran 18 % slower with six jobs per pixel)
+      const bool scans = c->search == SEARCH_LINEAR || c->search == SEARCH_LINEAR_LDS;
+      const bool walks_tree = !scans && c->n_nodes >= 32;
+      const uint32_t fewest = walks_tree ? (uint32_t)min_parts(n_rect, (size_t)c->n_cu * 1024) : 1u;
+      // Where a sample costs far more than the 24 bytes of traffic its storing adds (a tree walk, a scan over many
+      // spheres), every pixel may be cut, as far as the budget goes, the most expensive ones first.  Elsewhere
+      // only the few most expensive ones — or, in a frame with fewer than four pixels per lane, which balances
+      // only if most pixels may be cut (960x540: +15 %), all of them.
+      const bool heavy = walks_tree || (scans && c->n_spheres >= 64);
+      const size_t row_cap = split_rows() >= 0 ? (size_t)split_rows()
+                                                : (heavy || n_rect < (size_t)c->n_cu * 4096 ? n_rect : (size_t)65536);
       const uint32_t max_split = (uint32_t)(want > row_cap ? row_cap : want);
       const int splittable = p->rng_mode == RT_RNG_COUNTER && max_split > 0 ? 1 : 0;
       HIP_TRY(c->plan_parts.resize(n));
       HIP_TRY(c->plan_first.resize(n));
       HIP_TRY(c->plan_counts.resize(1));
       HIP_TRY(c->plan_total.resize(1));
-      HIP_TRY(c->plan_jobs.resize((size_t)n * (size_t)min_parts() + (size_t)lanes + 64));
+      HIP_TRY(c->plan_jobs.resize((size_t)n * (size_t)fewest + (size_t)lanes + 64));
       if (splittable) HIP_TRY(c->split_samples.resize((size_t)max_split * (size_t)main_samples * 3));
       size_t scan_bytes = 0;
       HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, c->plan_parts.p, c->plan_first.p, 0u, n, rocprim::plus<uint32_t>(), c->stream));
@@ -972,7 +990,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       const unsigned grid = (n + 255) / 256;
       rt_plan_cost_kernel<<<grid < 1024 ? grid : 1024, 256, 0, c->stream>>>(c->carry_cost.p, n, c->plan_total.p);
       rt_plan_count_kernel<<<grid, 256, 0, c->stream>>>(c->carry_cost.p, c->order_idx.p, n, c->plan_total.p, lanes, max_split, main_samples,
-                                                       splittable, (uint32_t)min_parts(), c->plan_parts.p);
+                                                       splittable, fewest, c->plan_parts.p);
       HIP_TRY(hipGetLastError());
       HIP_TRY(rocprim::exclusive_scan(c->scan_temp.p, scan_bytes, c->plan_parts.p, c->plan_first.p, 0u, n, rocprim::plus<uint32_t>(),
                                       c->stream));
@@ -987,11 +1005,12 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       mainp.n_jobs = c->plan_counts.p;
       mainp.split_samples = c->split_samples.p;
       mainp.main_samples = main_samples;
+      mainp.split_rows = n < max_split ? n : max_split;
       e = launch(mainp, p);
       if (e == hipSuccess && splittable) {
         const uint32_t cand = n < max_split ? n : max_split;
         rt_sum_split_kernel<<<(cand + 255) / 256, 256, 0, c->stream>>>(c->order_idx.p, c->plan_parts.p, cand, c->carry_colour.p,
-                                                                      c->split_samples.p, main_samples, p->tile_x0, p->tile_y0,
+                                                                      c->split_samples.p, main_samples, cand, p->tile_x0, p->tile_y0,
                                                                       tw, p->width, c->accum());
         e = hipGetLastError();
       }

@@ -105,8 +105,10 @@ struct render_args {
   // keeps the pixel's sum bit-identical to a sequential evaluation.
   const uint4* jobs;           // (rect pixel, first sample, end sample, split row or RT_JOB_WHOLE)
   const uint32_t* n_jobs;      // how many there are (computed on the device)
-  float* split_samples;        // split row r, sample s of the main pass: 3 floats at (r * main_samples + s) * 3
+  float* split_samples;        // split row r, sample s of the main pass: 3 floats at (s * split_rows + r) * 3 (sample-major:
+                               // the jobs a wave holds are neighbours in the order, and the sum reads whole planes)
   int main_samples;            // samples per pixel of the main pass
+  uint32_t split_rows;         // rows of split_samples
 };
 
 #define RT_JOB_WHOLE 0xFFFFFFFFu
@@ -356,10 +358,10 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
     if (split_row == RT_JOB_WHOLE) {
       colour = colour + alb;
     } else {
-      // rows of samples for the split pixels of the main pass; sample-major for a probe in sweeps, where every
-      // pixel has a row and neighbouring lanes hold neighbouring pixels
-      float* dst = A.split_samples + (A.pass == 3 ? (size_t)(s - P.sample_begin) * ((size_t)tw * (size_t)th) + (size_t)split_row
-                                                  : (size_t)split_row * (size_t)A.main_samples + (size_t)(s - P.sample_begin)) * 3;
+      // sample-major: plane s holds that sample of every row (split pixels of the main pass; every pixel of a pass
+      // in sweeps), so that lanes holding neighbouring rows write next to each other
+      const size_t rows = A.pass == 3 ? (size_t)tw * (size_t)th : (size_t)A.split_rows;
+      float* dst = A.split_samples + ((size_t)(s - P.sample_begin) * rows + (size_t)split_row) * 3;
       dst[0] = alb.x;
       dst[1] = alb.y;
       dst[2] = alb.z;
@@ -603,13 +605,15 @@ __global__ __launch_bounds__(256) void rt_plan_jobs_kernel(const uint32_t* order
 // probe pass carried, exactly as one lane would have added them.
 __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order, const uint32_t* parts, uint32_t n_candidates,
                                                           const float* carry_colour, const float* split_samples, int samples,
-                                                          int tile_x0, int tile_y0, int tile_w, int width, float* accum) {
+                                                          uint32_t n_rows, int tile_x0, int tile_y0, int tile_w, int width, float* accum) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_candidates || parts[i] <= 1u) return;
   const uint32_t rect_pixel = order[i];
   f3 colour = mk3(carry_colour[3 * (size_t)rect_pixel], carry_colour[3 * (size_t)rect_pixel + 1], carry_colour[3 * (size_t)rect_pixel + 2]);
-  const float* src = split_samples + (size_t)i * (size_t)samples * 3;
-  for (int s = 0; s < samples; s++) colour = colour + mk3(src[3 * s], src[3 * s + 1], src[3 * s + 2]);
+  for (int s = 0; s < samples; s++) {  // sample-major buffer: consecutive threads read consecutive rows
+    const float* src = split_samples + ((size_t)s * n_rows + i) * 3;
+    colour = colour + mk3(src[0], src[1], src[2]);
+  }
   const int x = tile_x0 + (int)(rect_pixel % (uint32_t)tile_w), y = tile_y0 + (int)(rect_pixel / (uint32_t)tile_w);
   float* dst = accum + 3 * ((size_t)y * (size_t)width + (size_t)x);
   dst[0] = colour.x;
