@@ -264,6 +264,28 @@ RT_API int rt_trace_batch(rt_ctx* ctx, const float* o_xyz, const float* d_xyz, s
 RT_API int rt_trace_batch_device(rt_ctx* ctx, const float* o_xyz, const float* d_xyz, size_t n,
                                  int32_t* id, float* t, float* nrm, int counted);
 
+/*
+ * rt_trace_batch_device for callers that cannot allocate: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no
+ * counterpart in the reference.  Same arguments (device pointers), same
+ * results bit for bit, asynchronous on the context's stream, no work counters;
+ * it calls no hipMalloc / hipFree and no allocating library routine.  The
+ * kernel's own working memory (the head of its ray queue and, for hierarchies
+ * read from HBM, the part of the lanes' traversal stacks that does not fit
+ * LDS) comes from a fixed array of RT_NOALLOC_SCRATCH_BYTES that every GPU the
+ * library runs on holds until the process ends.  Limits: at most
+ * RT_NOALLOC_MAX_RAYS rays per call (RT_ERR_INVALID beyond), and a hierarchy
+ * whose depth lets the stack overflow of at least one workgroup per compute
+ * unit fit the array (RT_ERR_INVALID otherwise: about depth 150 for the
+ * HBM-resident trees; scenes held in LDS and the linear scan always fit).
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU
+ * (two contexts, two streams) race; issue them one after another.
+ */
+#define RT_NOALLOC_SCRATCH_BYTES (64u << 20)
+#define RT_NOALLOC_MAX_RAYS 0x80000000ull
+RT_API int rt_trace_batch_noalloc(rt_ctx* ctx, const float* o_xyz, const float* d_xyz, size_t n,
+                                  int32_t* id, float* t, float* nrm);
+
 /* Wait for everything queued on the context's stream. */
 RT_API int rt_synchronize(rt_ctx* ctx);
 

@@ -199,6 +199,12 @@ class Renderer:
                                                    ctypes.c_void_p(id_ptr), ctypes.c_void_p(t_ptr),
                                                    ctypes.c_void_p(nrm_ptr), int(bool(counted))))
 
+    def trace_noalloc(self, o_ptr, d_ptr, n, id_ptr, t_ptr, nrm_ptr):
+        """rt_trace_batch_noalloc: the same batch without any allocation by the library (fixed per-GPU scratch)."""
+        self._check(self.lib.rt_trace_batch_noalloc(self.ctx, ctypes.c_void_p(o_ptr), ctypes.c_void_p(d_ptr), int(n),
+                                                    ctypes.c_void_p(id_ptr), ctypes.c_void_p(t_ptr),
+                                                    ctypes.c_void_p(nrm_ptr)))
+
     def synchronize(self):
         self._check(self.lib.rt_synchronize(self.ctx))
 

@@ -83,6 +83,23 @@ constexpr int kMaxBig = 8;
 
 }  // namespace
 
+// ---- fixed scratch of rt_trace_batch_noalloc ---------------------------------
+// The closest-hit kernel needs device memory beyond its inputs and outputs: the head of its ray queue and, for trees
+// read from HBM, the part of the lanes' traversal stacks that does not fit LDS.  rt_trace_batch_device takes both from
+// buffers the context allocates on demand; the entry point that must not allocate takes them from this array, which
+// every GPU the library runs on holds (at its own address) until the process ends.
+//   [0, kNoAllocHeaderBytes)       queue head (8 bytes used)
+//   [kNoAllocHeaderBytes, end)     traversal-stack overflow, one slice per workgroup of the launch
+static __device__ __align__(256) unsigned char rt_noalloc_scratch[RT_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr size_t kNoAllocHeaderBytes = 256;
+constexpr int kMaxDevices = 64;
+// Device address of rt_noalloc_scratch on each device, looked up by rt_init with that device current (the array's
+// name is only a host-side handle: kernels and memsets get these addresses).
+unsigned char* g_noalloc_scratch[kMaxDevices] = {};
+}  // namespace
+
 // Work arrays of the hierarchy build.  They stay with the context between uploads (a scene that is
 // rebuilt every frame should not pay fifteen allocations per build) unless they are large.
 struct lbvh_scratch {
@@ -743,6 +760,23 @@ hipError_t attach_overflow(rt_ctx* c, long long blocks, scene_dev& sc) {
   return hipSuccess;
 }
 
+// The same from a fixed piece of memory: the launch is cut down to the workgroups whose slices fit (the kernel is
+// persistent, any number of workgroups drains the queue).  Returns false when not even one workgroup per CU fits.
+template <int SEARCH>
+bool attach_overflow_fixed(rt_ctx* c, long long& blocks, scene_dev& sc, unsigned char* base, size_t bytes) {
+  using T = search_traits<SEARCH>;
+  if (!T::tree || T::lds) return true;
+  const int cap = 3 * (c->depth / 2 + 2) - T::stack;
+  if (cap <= 0) return true;
+  const size_t per_block = (size_t)T::waves * (size_t)cap * 64 * sizeof(uint32_t);
+  const long long fit = (long long)(bytes / per_block);
+  if (fit < (long long)c->n_cu && fit < blocks) return false;
+  if (blocks > fit) blocks = fit;
+  sc.ovf = reinterpret_cast<uint32_t*>(base);
+  sc.ovf_cap = cap;
+  return true;
+}
+
 template <int SEARCH, int RNG, bool COUNTED>
 hipError_t launch_render_one(rt_ctx* c, const rt_params* p, hipStream_t st, render_args a) {
   using T = search_traits<SEARCH>;
@@ -774,8 +808,10 @@ hipError_t launch_render(rt_ctx* c, const rt_params* p, bool counted, hipStream_
                  : launch_render_one<SEARCH, RT_RNG_COUNTER, false>(c, p, st, a);
 }
 
+// `fixed` (nullable): memory the traversal-stack overflow must come from instead of a buffer of the context
+// (fixed_bytes of it); hipErrorOutOfMemory when the tree's depth needs more than it holds.
 template <int SEARCH, bool COUNTED>
-hipError_t launch_trace_one(rt_ctx* c, hipStream_t st, trace_args a) {
+hipError_t launch_trace_one(rt_ctx* c, hipStream_t st, trace_args a, unsigned char* fixed, size_t fixed_bytes) {
   using T = search_traits<SEARCH>;
   const size_t lds = search_lds_bytes<SEARCH>(counts_of(c));
   hipError_t e = allow_lds(rt_trace_kernel<SEARCH, COUNTED>, lds);
@@ -788,15 +824,21 @@ hipError_t launch_trace_one(rt_ctx* c, hipStream_t st, trace_args a) {
   const long long needed = (long long)((a.n + T::threads - 1) / T::threads);
   if (blocks > needed) blocks = needed;
   if (blocks < 1) blocks = 1;
-  e = attach_overflow<SEARCH>(c, blocks, a.sc);
-  if (e != hipSuccess) return e;
+  if (fixed) {
+    if (!attach_overflow_fixed<SEARCH>(c, blocks, a.sc, fixed, fixed_bytes)) return hipErrorOutOfMemory;
+  } else {
+    e = attach_overflow<SEARCH>(c, blocks, a.sc);
+    if (e != hipSuccess) return e;
+  }
   rt_trace_kernel<SEARCH, COUNTED><<<dim3((unsigned)blocks), T::threads, lds, st>>>(a);
   return hipGetLastError();
 }
 
 template <int SEARCH>
-hipError_t launch_trace(rt_ctx* c, bool counted, hipStream_t st, const trace_args& a) {
-  return counted ? launch_trace_one<SEARCH, true>(c, st, a) : launch_trace_one<SEARCH, false>(c, st, a);
+hipError_t launch_trace(rt_ctx* c, bool counted, hipStream_t st, const trace_args& a, unsigned char* fixed = nullptr,
+                        size_t fixed_bytes = 0) {
+  return counted ? launch_trace_one<SEARCH, true>(c, st, a, fixed, fixed_bytes)
+                 : launch_trace_one<SEARCH, false>(c, st, a, fixed, fixed_bytes);
 }
 
 int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
@@ -1045,6 +1087,11 @@ int rt_init(int device, rt_ctx** out) {
                 e != hipSuccess ? hipGetErrorString(e) : "device count 0");
   if (device < 0 || device >= n) return fail(RT_ERR_INVALID, "device %d out of range [0,%d)", device, n);
   HIP_TRY(hipSetDevice(device));
+  if (device < kMaxDevices && !g_noalloc_scratch[device]) {  // once per device, with that device current
+    void* ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(rt_noalloc_scratch)));
+    g_noalloc_scratch[device] = static_cast<unsigned char*>(ptr);
+  }
   rt_ctx* c = new rt_ctx();
   c->device = device;
   hipDeviceProp_t prop;
@@ -1370,6 +1417,58 @@ int rt_trace_batch_device(rt_ctx* c, const float* o_xyz, const float* d_xyz, siz
     case SEARCH_TREE_GLB_NODE: e = launch_trace<SEARCH_TREE_GLB_NODE>(c, counted != 0, c->stream, a); break;
     case SEARCH_LINEAR_LDS: e = launch_trace<SEARCH_LINEAR_LDS>(c, counted != 0, c->stream, a); break;
     default: e = launch_trace<SEARCH_LINEAR>(c, counted != 0, c->stream, a); break;
+  }
+  if (e != hipSuccess) return fail(RT_ERR_DEVICE, "trace launch: %s", hipGetErrorString(e));
+  c->last_kernel = search_name(c->search, false);
+  HIP_TRY(hipEventRecord(c->ev_k1, c->stream));
+  c->have_kernel_time = true;
+  return RT_OK;
+}
+
+// rt_trace_batch_device without a single allocation: queue head and traversal-stack overflow live in the device's
+// copy of rt_noalloc_scratch (address looked up once by rt_init).
+int rt_trace_batch_noalloc(rt_ctx* c, const float* o_xyz, const float* d_xyz, size_t n, int32_t* id, float* t, float* nrm) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!c->have_scene) return fail(RT_ERR_STATE, "rt_trace_batch_noalloc before rt_scene_upload");
+  if (n == 0) return RT_OK;
+  if (!o_xyz || !d_xyz || !id || !t || !nrm) return fail(RT_ERR_INVALID, "null ray or result pointer");
+  if (n > (size_t)RT_NOALLOC_MAX_RAYS)
+    return fail(RT_ERR_INVALID, "rt_trace_batch_noalloc takes at most %llu rays per call, got %zu",
+                (unsigned long long)RT_NOALLOC_MAX_RAYS, n);
+  unsigned char* scratch = c->device < kMaxDevices ? g_noalloc_scratch[c->device] : nullptr;
+  if (!scratch) return fail(RT_ERR_STATE, "device %d has no fixed scratch (rt_init looks it up for devices below %d)", c->device, kMaxDevices);
+  trace_args a;
+  a.sc = c->view();
+  a.o_xyz = o_xyz;
+  a.d_xyz = d_xyz;
+  a.n = n;
+  a.id = id;
+  a.t = t;
+  a.nrm = nrm;
+  a.counters = nullptr;
+  a.queue = reinterpret_cast<unsigned long long*>(scratch);
+  a.vote = trace_vote();
+  a.leaf_vote = leaf_vote();
+  // the array keeps what the last call left: the queue head must start at zero (the overflow slices are written
+  // before they are read)
+  HIP_TRY(hipMemsetAsync(scratch, 0, sizeof(unsigned long long), c->stream));
+  HIP_TRY(hipEventRecord(c->ev_k0, c->stream));
+  unsigned char* ovf = scratch + kNoAllocHeaderBytes;
+  const size_t ovf_bytes = (size_t)RT_NOALLOC_SCRATCH_BYTES - kNoAllocHeaderBytes;
+  hipError_t e;
+  switch (c->search) {
+    case SEARCH_TREE_LDS_RAY: e = launch_trace<SEARCH_TREE_LDS_RAY>(c, false, c->stream, a, ovf, ovf_bytes); break;
+    case SEARCH_TREE_LDS_NODE: e = launch_trace<SEARCH_TREE_LDS_NODE>(c, false, c->stream, a, ovf, ovf_bytes); break;
+    case SEARCH_TREE_GLB_RAY: e = launch_trace<SEARCH_TREE_GLB_RAY>(c, false, c->stream, a, ovf, ovf_bytes); break;
+    case SEARCH_TREE_GLB_NODE: e = launch_trace<SEARCH_TREE_GLB_NODE>(c, false, c->stream, a, ovf, ovf_bytes); break;
+    case SEARCH_LINEAR_LDS: e = launch_trace<SEARCH_LINEAR_LDS>(c, false, c->stream, a, ovf, ovf_bytes); break;
+    default: e = launch_trace<SEARCH_LINEAR>(c, false, c->stream, a, ovf, ovf_bytes); break;
+  }
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    return fail(RT_ERR_INVALID, "the hierarchy (depth %d) needs more traversal-stack overflow than the %u-byte fixed scratch "
+                "holds for one workgroup per CU; use rt_trace_batch_device", c->depth, (unsigned)RT_NOALLOC_SCRATCH_BYTES);
   }
   if (e != hipSuccess) return fail(RT_ERR_DEVICE, "trace launch: %s", hipGetErrorString(e));
   c->last_kernel = search_name(c->search, false);

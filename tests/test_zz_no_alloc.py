@@ -1,0 +1,62 @@
+"""rt_trace_batch_noalloc — the closest-hit batch for callers that cannot allocate — against
+rt_trace_batch_device, through the C ABI.  Bit-exact ids, t and normals; two calls in a row, the second with a
+smaller input (the per-GPU scratch keeps what the first call left); free device memory unchanged across the calls."""
+import numpy as np
+import pytest
+
+import raytrace_amd as rt
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_rays(torch, seed, n):
+    o, d = rt.gen_rays(seed, 0, n)
+    return torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+
+
+def _outputs(torch, n):
+    return (torch.full((n,), -7, dtype=torch.int32, device="cuda"), torch.full((n,), -7.0, dtype=torch.float32, device="cuda"),
+            torch.full((n, 3), -7.0, dtype=torch.float32, device="cuda"))
+
+
+def _same(a, b):
+    return bool((a.cpu().numpy().view(np.uint32) == b.cpu().numpy().view(np.uint32)).all())
+
+
+@pytest.mark.parametrize("scene_id,n_spheres,accel,kernel", [
+    (rt.SCENE_CLOUD, 60000, rt.ACCEL_LBVH, "rt_trace_kernel<lbvh4,hbm,pad_node>"),   # stack overflow slices in the scratch
+    (rt.SCENE_RANDOM_SPHERES, 0, rt.ACCEL_LBVH, "rt_trace_kernel<lbvh4,lds,pad_ray>"),
+    (rt.SCENE_RANDOM_SPHERES, 0, rt.ACCEL_LINEAR, "rt_trace_kernel<linear,lds>"),
+])
+def test_noalloc_equals_allocating_entry_point(scene_id, n_spheres, accel, kernel):
+    import torch
+    scene = rt.build_scene(scene_id, n=n_spheres, seed=11)
+    r = rt.Renderer(0)   # a fresh context: the first compute call on it is the one that must not allocate
+    try:
+        r.upload(scene, accel)
+        sizes = (300_000, 70_001)
+        rays = [_device_rays(torch, 500 + i, n) for i, n in enumerate(sizes)]
+        got = [_outputs(torch, n) for n in sizes]
+        want = [_outputs(torch, n) for n in sizes]
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        for (o, d), (ids, t, nrm), n in zip(rays, got, sizes):   # two calls in a row, the second smaller
+            r.trace_noalloc(o.data_ptr(), d.data_ptr(), n, ids.data_ptr(), t.data_ptr(), nrm.data_ptr())
+        r.synchronize()
+        assert r.last_kernel_ms()[1] == kernel
+        assert torch.cuda.mem_get_info()[0] == free_before, "the call changed the amount of free device memory"
+        for (o, d), (ids, t, nrm), n in zip(rays, want, sizes):
+            r.trace_device(o.data_ptr(), d.data_ptr(), n, ids.data_ptr(), t.data_ptr(), nrm.data_ptr())
+        r.synchronize()
+        for g, w, n in zip(got, want, sizes):
+            assert int((w[0] >= 0).sum()) > n // 1000, "the batch should hit something"
+            assert torch.equal(g[0], w[0]), f"{int((g[0] != w[0]).sum())} ids differ"
+            assert _same(g[1], w[1]) and _same(g[2], w[2])
+        # beyond the stated maximum: refused before anything is touched
+        o, d = rays[1]
+        ids, t, nrm = got[1]
+        with pytest.raises(rt.RtError) as err:
+            r.trace_noalloc(o.data_ptr(), d.data_ptr(), (1 << 31) + 1, ids.data_ptr(), t.data_ptr(), nrm.data_ptr())
+        assert "at most" in str(err.value)
+    finally:
+        r.close()
