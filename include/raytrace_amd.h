@@ -55,7 +55,8 @@ enum {
 /* Random number source of rt_render. */
 enum {
   /* xorshift32 seeded once per pixel and carried across that pixel's samples
-   * and bounces (testFragment.fs:105-110, 326-345).  Needs sample_begin == 0. */
+   * and bounces (testFragment.fs:105-110, 326-345).  Needs sample_begin == 0
+   * (RT_ERR_INVALID otherwise: a later range would repeat the first one's draws). */
   RT_RNG_XORSHIFT_REF = 0,
   /* Counter-based: the stream is a function of (seed, pixel, sample) only, so
    * an image does not depend on how it is split into tiles or sample ranges. */
@@ -92,7 +93,9 @@ typedef struct rt_params {
   uint32_t reserved0;
   /* RT_RNG_XORSHIFT_REF only: width*height words, row y of the image at
    * [y*width, (y+1)*width): the bits of (tex.r + tex.g + tex.b) that the shader
-   * reads at testFragment.fs:105-106.  Host pointer; NULL means all zero.       */
+   * reads at testFragment.fs:105-106.  Host pointer; NULL means all zero.  It is
+   * copied to the device asynchronously: keep it valid and unchanged until the
+   * next rt_synchronize / rt_readback on the context.                           */
   const uint32_t* seed_tex;
 } rt_params;
 
@@ -191,11 +194,27 @@ RT_API int rt_scene_upload(rt_ctx* ctx, const void* spheres_std140, int n_sphere
  * sample_end) of every pixel of the tile to the context's FP32 accumulator
  * (allocated and zeroed when the image size changes or rt_clear is called).
  * Asynchronous on the context's stream.
+ * The sample count rt_readback divides by is end - begin of the union of the
+ * ranges rendered since the last rt_clear: render each sample of a pixel once,
+ * in ranges without gaps, and the same ranges over every tile (or state the
+ * count with rt_set_accumulated_samples).
  */
 RT_API int rt_render(rt_ctx* ctx, const rt_params* p);
 
 /* Same render with the work counters switched on (slower; not for timing). */
 RT_API int rt_render_counted(rt_ctx* ctx, const rt_params* p);
+
+/*
+ * Device memory rt_render may take for its schedule (no counterpart in the
+ * reference, whose draw call needs none): split_bytes for the per-sample
+ * radiance of pixels cut into several jobs (default 32 GiB), probe_bytes for
+ * that of the cost-probe pass (default 4 GiB); 0 keeps a default.  Whatever the
+ * budgets, a render takes at most half / an eighth of the memory the device
+ * can still give, falls back to schedules that need less when an allocation
+ * fails, and gives the image's bits regardless: the budgets trade speed only.
+ * Buffers held beyond a new budget are freed by this call.
+ */
+RT_API int rt_set_scratch_budget(rt_ctx* ctx, size_t split_bytes, size_t probe_bytes);
 
 /* Zero the accumulator and the accumulated-sample count. */
 RT_API int rt_clear(rt_ctx* ctx);
@@ -315,6 +334,25 @@ RT_API int rt_lbvh_depth(rt_ctx* ctx);
  * seed_tex: width*height words, host memory.                                 */
 RT_API int rt_seed_texture(rt_ctx* ctx, int width, int height, float grid_size, float contrast, int layers,
                            float lacunarity, uint32_t* seed_tex);
+
+/*
+ * Replaces: perlin(float x, float y), perlin.h:59-85 — the reference's 2-D
+ * gradient noise (linear interpolation, result 0.5 * v + 0.5), evaluated by
+ * the same device function the noise-textured material (RT_MAT_PERLIN_
+ * LAMBERTIAN) calls.  xy: n points, 2 floats each; value: n floats; host
+ * pointers.  use_table != 0 reads the gradients of lattice points inside
+ * [-2048, 2048)^2 from the context's precomputed table (built on first use),
+ * as the render kernels do; 0 computes every gradient on the spot.  Both give
+ * the bits of the reference's function.
+ */
+RT_API int rt_eval_perlin(rt_ctx* ctx, const float* xy, size_t n, int use_table, float* value);
+
+/*
+ * Replaces: randomGradient(int ix, int iy), perlin.h:31-43.  ixy: n lattice
+ * points, 2 ints each; gxy: n gradients, 2 floats each (x = cos, y = sin of
+ * the hashed angle); host pointers.
+ */
+RT_API int rt_eval_perlin_gradient(rt_ctx* ctx, const int32_t* ixy, size_t n, float* gxy);
 
 /* Number of HIP devices visible (0 if none or the runtime cannot start). */
 RT_API int rt_device_count(void);

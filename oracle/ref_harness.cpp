@@ -12,6 +12,10 @@
 // Output (stdout, one JSON object): every float as its IEEE-754 bit pattern.
 //   perlin        [[x_bits, y_bits, perlin(x,y)_bits], ...]      perlin.h:59-85
 //   gradients     [[ix, iy, gx_bits, gy_bits], ...]              perlin.h:31-43
+//   perlin_far    the same as perlin, for points whose lattice cell lies far from the origin
+//                 or on either side of +-2048 (where a consumer may switch between a
+//                 precomputed gradient table and gradients computed on the spot)
+//   gradients_far the same as gradients, for such lattice points
 //   camera_c1/c2  the uniform vectors of raytrace.cpp:341-366 computed with the
 //                 reference's own vec3 operators
 //   list          hittable_list bookkeeping after three add() calls
@@ -137,6 +141,44 @@ int main() {
       vector2 g = randomGradient(ix * 131, iy * 77 + 1);
       std::printf("%s    [%d, %d, %u, %u]", first ? "" : ",\n", ix * 131, iy * 77 + 1, bits(g.x), bits(g.y));
       first = false;
+    }
+  }
+  std::printf("\n  ],\n");
+
+  // Far from the origin, and around +-2048 in either coordinate.
+  std::printf("  \"perlin_far\": [\n");
+  first = true;
+  {
+    const float edge[] = {-2049.5f, -2048.5f, -2047.5f, -2046.25f, 2045.75f, 2046.5f, 2047.5f, 2048.5f, 2049.25f};
+    const float mid[] = {-3.25f, 0.5f, 7.75f, -2048.0f, 2047.0f, 2048.0f};
+    for (float a : edge) {
+      for (float b : mid) {
+        std::printf("%s    [%u, %u, %u]", first ? "" : ",\n", bits(a), bits(b), bits(perlin(a, b)));
+        first = false;
+        std::printf(",\n    [%u, %u, %u]", bits(b), bits(a), bits(perlin(b, a)));
+      }
+      for (float b : edge) std::printf(",\n    [%u, %u, %u]", bits(a), bits(b), bits(perlin(a, b)));
+    }
+    for (int i = 1; i <= 60; i++) {
+      const float x = 2048.0f + 37.37f * (float)(i * i), y = -2048.0f - 1234.5f * (float)i + 0.125f;
+      std::printf(",\n    [%u, %u, %u]", bits(x), bits(y), bits(perlin(x, y)));
+      std::printf(",\n    [%u, %u, %u]", bits(-x), bits(0.3f * (float)i), bits(perlin(-x, 0.3f * (float)i)));
+      std::printf(",\n    [%u, %u, %u]", bits(0.7f * (float)i), bits(-y), bits(perlin(0.7f * (float)i, -y)));
+    }
+    const float big[] = {1.0e6f, -1.0e6f, 16777215.0f, -16777215.0f, 1.0e9f, -1.0e9f};  // beyond 2^24 the fraction is zero
+    for (float a : big) std::printf(",\n    [%u, %u, %u]", bits(a + 0.5f), bits(-a), bits(perlin(a + 0.5f, -a)));
+  }
+  std::printf("\n  ],\n");
+  std::printf("  \"gradients_far\": [\n");
+  first = true;
+  {
+    const int pts[] = {-2147483647 - 1, -2147483647, -1000000007, -65536, -2049, -2048, -2047, -1, 0, 1, 2046, 2047, 2048, 2049, 65535, 123456789, 2147483646, 2147483647};
+    for (int ix : pts) {
+      for (int iy : {-2049, -2048, 0, 2047, 2048, 99991, -2147483647 - 1, 2147483647}) {
+        vector2 g = randomGradient(ix, iy);
+        std::printf("%s    [%d, %d, %u, %u]", first ? "" : ",\n", ix, iy, bits(g.x), bits(g.y));
+        first = false;
+      }
     }
   }
   std::printf("\n  ],\n");

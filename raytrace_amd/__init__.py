@@ -17,6 +17,7 @@ ACCEL_LINEAR, ACCEL_LBVH = 0, 1
 RNG_XORSHIFT_REF, RNG_COUNTER = 0, 1
 SCENE_DEFAULT, SCENE_RANDOM_SPHERES, SCENE_PERLIN, SCENE_CLOUD = 0, 1, 2, 3
 MATERIAL_BUFFER, SPHERE_BUFFER = 1, 2
+MAT_NOTHING, MAT_LAMBERTIAN, MAT_METALLIC, MAT_DIALECTRIC, MAT_PERLIN_LAMBERTIAN = 0, 1, 2, 3, 4
 RECORD_BYTES = 32
 
 
@@ -165,6 +166,10 @@ class Renderer:
         self._check(self.lib.rt_set_accumulator(self.ctx, ctypes.c_void_p(device_ptr), int(width), int(height)))
         self.width, self.height = width, height
 
+    def set_scratch_budget(self, split_bytes=0, probe_bytes=0):
+        """Device memory the render schedule may take (0 = default); see rt_set_scratch_budget."""
+        self._check(self.lib.rt_set_scratch_budget(self.ctx, int(split_bytes), int(probe_bytes)))
+
     def set_accumulated_samples(self, samples):
         self._check(self.lib.rt_set_accumulated_samples(self.ctx, int(samples)))
 
@@ -204,6 +209,20 @@ class Renderer:
         self._check(self.lib.rt_trace_batch_noalloc(self.ctx, ctypes.c_void_p(o_ptr), ctypes.c_void_p(d_ptr), int(n),
                                                     ctypes.c_void_p(id_ptr), ctypes.c_void_p(t_ptr),
                                                     ctypes.c_void_p(nrm_ptr)))
+
+    def eval_perlin(self, xy, use_table=True):
+        """perlin(x, y) of perlin.h:59-85 on the device for float32 [n,2] points."""
+        xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+        out = np.empty(xy.shape[0], dtype=np.float32)
+        self._check(self.lib.rt_eval_perlin(self.ctx, xy.ctypes.data, xy.shape[0], int(bool(use_table)), out.ctypes.data))
+        return out
+
+    def eval_perlin_gradient(self, ixy):
+        """randomGradient(ix, iy) of perlin.h:31-43 on the device for int32 [n,2] lattice points -> float32 [n,2]."""
+        ixy = np.ascontiguousarray(ixy, dtype=np.int32).reshape(-1, 2)
+        out = np.empty((ixy.shape[0], 2), dtype=np.float32)
+        self._check(self.lib.rt_eval_perlin_gradient(self.ctx, ixy.ctypes.data, ixy.shape[0], out.ctypes.data))
+        return out
 
     def synchronize(self):
         self._check(self.lib.rt_synchronize(self.ctx))

@@ -54,6 +54,14 @@ struct dev_buf {
     if (e == hipSuccess) n = count; else p = nullptr;
     return e;
   }
+  // resize() for the large per-frame buffers: one held from a much larger frame is given back first, and running out
+  // of memory is reported without leaving the error pending
+  hipError_t fit(size_t count) {
+    if (p && n > 4 * count && n * sizeof(T) > ((size_t)64 << 20)) release();
+    const hipError_t e = resize(count);
+    if (e == hipErrorOutOfMemory) (void)hipGetLastError();
+    return e;
+  }
   hipError_t upload(const std::vector<T>& v, hipStream_t st) {
     hipError_t e = resize(v.empty() ? 1 : v.size());
     if (e != hipSuccess || v.empty()) return e;
@@ -173,6 +181,7 @@ struct rt_ctx {
   dev_buf<float> split_samples, probe_samples;
   dev_buf<unsigned char> scan_temp;
   int n_cu = 0;
+  size_t split_budget = 0, probe_budget = 0;  // rt_set_scratch_budget; 0: the defaults
   dev_buf<unsigned long long> counters;
   dev_buf<float> out_linear;
   dev_buf<uint8_t> out_rgb8;
@@ -668,6 +677,22 @@ size_t split_budget_bytes() {
   return v;
 }
 
+// What the two per-sample stores may take in this render: the context's budgets (rt_set_scratch_budget, else the
+// defaults), and never more than a share of what the device can still give — free memory plus what the two buffers
+// already hold.
+void scratch_budgets(rt_ctx* c, size_t& split, size_t& probe) {
+  split = c->split_budget ? c->split_budget : split_budget_bytes();
+  probe = c->probe_budget ? c->probe_budget : kProbeBudgetBytes;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  const size_t avail = free_b + (c->split_samples.n + c->probe_samples.n) * sizeof(float);
+  split = std::min(split, avail / 2);
+  probe = std::min(probe, avail / 8);
+}
+
 // Sweeps of the probe pass (RT_PROBE_SWEEPS overrides, 1 = unsplit probe).
 int probe_sweeps() {
   static int v = [] {
@@ -722,6 +747,16 @@ int check_ctx(rt_ctx* c) {
   return RT_OK;
 }
 
+// The gradient table of the noise texture does not depend on the scene: built once per context.
+int ensure_noise_table(rt_ctx* c) {
+  if (c->perlin_grad.p) return RT_OK;
+  const size_t side = 2 * (size_t)kPerlinHalf;
+  HIP_TRY(c->perlin_grad.resize(side * side));
+  rt_perlin_table_kernel<<<(unsigned)((side * side + 255) / 256), 256, 0, c->stream>>>(c->perlin_grad.p, kPerlinHalf);
+  HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
 int check_params(rt_ctx* c, const rt_params* p) {
   if (!p) return fail(RT_ERR_INVALID, "null params");
   if (!c->have_scene) return fail(RT_ERR_STATE, "rt_render before rt_scene_upload");
@@ -733,6 +768,11 @@ int check_params(rt_ctx* c, const rt_params* p) {
                 p->width, p->height);
   if (p->sample_begin < 0 || p->sample_end < p->sample_begin) return fail(RT_ERR_INVALID, "bad sample range");
   if (p->rng_mode != RT_RNG_XORSHIFT_REF && p->rng_mode != RT_RNG_COUNTER) return fail(RT_ERR_INVALID, "bad rng_mode");
+  // the reference's generator is seeded per pixel and runs through the pixel's samples from the first one
+  // (fs:105-110): a range that starts later would draw the first range's numbers again
+  if (p->rng_mode == RT_RNG_XORSHIFT_REF && p->sample_begin != 0)
+    return fail(RT_ERR_INVALID, "RT_RNG_XORSHIFT_REF renders samples from 0 only (sample_begin = %d): use RT_RNG_COUNTER for sample ranges",
+                p->sample_begin);
   return RT_OK;
 }
 
@@ -926,11 +966,14 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   hipError_t e;
   // Few samples, counter RNG: the frame as a whole is rendered in sweeps (short jobs in tile order, per-sample
   // radiance summed in order afterwards) — a pixel per job would end with the expensive pixels' lanes working alone.
-  const bool whole_in_sweeps = !two_pass && two_pass_enabled() && p->rng_mode == RT_RNG_COUNTER && probe_sweeps() > 1 &&
-                               n_samples >= 2 && n_rect >= 16384 &&
-                               n_rect * (size_t)n_samples * 3 * sizeof(float) <= kProbeBudgetBytes;
+  size_t split_budget, probe_budget;
+  scratch_budgets(c, split_budget, probe_budget);
+  bool whole_in_sweeps = !two_pass && two_pass_enabled() && p->rng_mode == RT_RNG_COUNTER && probe_sweeps() > 1 &&
+                         n_samples >= 2 && n_rect >= 16384 &&
+                         n_rect * (size_t)n_samples * 3 * sizeof(float) <= probe_budget;
+  // (a store that cannot be had costs speed, never the frame: the plain schedules below need none)
+  if (whole_in_sweeps && c->probe_samples.fit(n_rect * (size_t)n_samples * 3) != hipSuccess) whole_in_sweeps = false;
   if (whole_in_sweeps) {
-    HIP_TRY(c->probe_samples.resize(n_rect * (size_t)n_samples * 3));
     render_args sw = a;
     sw.pass = 3;
     sw.sweeps = probe_sweeps() < n_samples ? probe_sweeps() : n_samples;
@@ -964,14 +1007,14 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
     // Counter RNG: the probe runs in sweeps (see render_args), its samples in a buffer of their own.
     bool swept = p->rng_mode == RT_RNG_COUNTER && probe_sweeps() > 1;
     int n_probe = probe_samples(n_samples, swept);
-    if (swept && n_rect * (size_t)n_probe * 3 * sizeof(float) > kProbeBudgetBytes) {
+    if (swept && (n_rect * (size_t)n_probe * 3 * sizeof(float) > probe_budget ||
+                  c->probe_samples.fit(n_rect * (size_t)n_probe * 3) != hipSuccess)) {
       swept = false;
       n_probe = probe_samples(n_samples, false);
     }
     const int sweeps = probe_sweeps() < n_probe ? probe_sweeps() : n_probe;
     probe.p.sample_end = p->sample_begin + n_probe;
     if (swept) {
-      HIP_TRY(c->probe_samples.resize(n_rect * (size_t)n_probe * 3));
       HIP_TRY(hipMemsetAsync(c->carry_cost.p, 0, n_rect * sizeof(uint32_t), c->stream));
       probe.pass = 3;
       probe.sweeps = sweeps;
@@ -1003,7 +1046,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       const uint32_t n = (uint32_t)n_rect;
       // a job should be a small fraction (1 / split_fineness()) of a lane's fair share of the frame
       const uint32_t lanes = (uint32_t)c->n_cu * 1024u * (uint32_t)split_fineness();
-      size_t want = split_budget_bytes() / ((size_t)main_samples * 3 * sizeof(float));
+      size_t want = split_budget / ((size_t)main_samples * 3 * sizeof(float));
       // (only where rays walk a tree worth the name: the scan and a tree of a few spheres gain nothing from
       // neighbouring rays, and every sample stored and read back costs them 24 bytes of traffic — the two-sphere
       // noise scene ran 18 % slower with six jobs per pixel)
@@ -1017,14 +1060,16 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       const bool heavy = walks_tree || (scans && c->n_spheres >= 64);
       const size_t row_cap = split_rows() >= 0 ? (size_t)split_rows()
                                                 : (heavy || n_rect < (size_t)c->n_cu * 4096 ? n_rect : (size_t)65536);
-      const uint32_t max_split = (uint32_t)(want > row_cap ? row_cap : want);
-      const int splittable = p->rng_mode == RT_RNG_COUNTER && max_split > 0 ? 1 : 0;
+      uint32_t max_split = (uint32_t)(want > row_cap ? row_cap : want);
+      if (p->rng_mode != RT_RNG_COUNTER) max_split = 0;
+      // the store of the cut pixels' samples: when the device cannot give it, fewer pixels are cut, in the end none
+      while (max_split > 0 && c->split_samples.fit((size_t)max_split * (size_t)main_samples * 3) != hipSuccess) max_split /= 2;
+      const int splittable = max_split > 0 ? 1 : 0;
       HIP_TRY(c->plan_parts.resize(n));
       HIP_TRY(c->plan_first.resize(n));
       HIP_TRY(c->plan_counts.resize(1));
       HIP_TRY(c->plan_total.resize(1));
       HIP_TRY(c->plan_jobs.resize((size_t)n * (size_t)fewest + (size_t)lanes + 64));
-      if (splittable) HIP_TRY(c->split_samples.resize((size_t)max_split * (size_t)main_samples * 3));
       size_t scan_bytes = 0;
       HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, c->plan_parts.p, c->plan_first.p, 0u, n, rocprim::plus<uint32_t>(), c->stream));
       HIP_TRY(c->scan_temp.resize(scan_bytes > 0 ? scan_bytes : 1));
@@ -1186,11 +1231,9 @@ int rt_scene_upload(rt_ctx* c, const void* spheres_std140, int n_spheres, const 
   HIP_TRY(c->mat_a.upload(mat_a, c->stream));
   c->have_noise = false;
   for (size_t i = 0; i < nm; i++) c->have_noise = c->have_noise || mat_type[i] == RT_MAT_PERLIN_LAMBERTIAN;
-  if (c->have_noise && !c->perlin_grad.p) {  // the table does not depend on the scene: built once per context
-    const size_t side = 2 * (size_t)kPerlinHalf;
-    HIP_TRY(c->perlin_grad.resize(side * side));
-    rt_perlin_table_kernel<<<(unsigned)((side * side + 255) / 256), 256, 0, c->stream>>>(c->perlin_grad.p, kPerlinHalf);
-    HIP_TRY(hipGetLastError());
+  if (c->have_noise) {
+    rc = ensure_noise_table(c);
+    if (rc) return rc;
   }
 
   // Hierarchy input: the few spheres far larger than the rest go to an exact
@@ -1303,6 +1346,18 @@ int rt_set_accumulator(rt_ctx* c, void* device_rgb, int width, int height) {
   }
   c->samples_lo = c->samples_hi = 0;
   c->samples_override = -1;
+  return RT_OK;
+}
+
+int rt_set_scratch_budget(rt_ctx* c, size_t split_bytes, size_t probe_bytes) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->split_budget = split_bytes;
+  c->probe_budget = probe_bytes;
+  // what is held beyond the new budgets goes back to the device now
+  if (split_bytes && c->split_samples.n * sizeof(float) > split_bytes) c->split_samples.release();
+  if (probe_bytes && c->probe_samples.n * sizeof(float) > probe_bytes) c->probe_samples.release();
   return RT_OK;
 }
 
@@ -1533,6 +1588,61 @@ int rt_trace_batch(rt_ctx* c, const float* o_xyz, const float* d_xyz, size_t n, 
   if (rc != RT_OK) return rc;
   if (e == hipSuccess) e = s0 != hipSuccess ? s0 : (s1 != hipSuccess ? s1 : s2);
   if (e != hipSuccess) return fail(RT_ERR_DEVICE, "ray batch transfer: %s", hipGetErrorString(e));
+  return RT_OK;
+}
+
+int rt_eval_perlin(rt_ctx* c, const float* xy, size_t n, int use_table, float* value) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (n == 0) return RT_OK;
+  if (!xy || !value) return fail(RT_ERR_INVALID, "null point or result pointer");
+  if (n > ((size_t)1 << 28)) return fail(RT_ERR_INVALID, "too many points");
+  if (use_table) {
+    rc = ensure_noise_table(c);
+    if (rc) return rc;
+  }
+  dev_buf<float2> in;
+  dev_buf<float> out;
+  hipError_t e = in.resize(n);
+  if (e == hipSuccess) e = out.resize(n);
+  if (e == hipSuccess) e = hipMemcpyAsync(in.p, xy, n * sizeof(float2), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    perlin_table tab;
+    tab.grad = use_table ? c->perlin_grad.p : nullptr;
+    tab.half = kPerlinHalf;
+    rt_eval_perlin_kernel<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(in.p, n, tab, out.p);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(value, out.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+  const hipError_t s = hipStreamSynchronize(c->stream);
+  in.release();
+  out.release();
+  if (e == hipSuccess) e = s;
+  if (e != hipSuccess) return fail(RT_ERR_DEVICE, "rt_eval_perlin: %s", hipGetErrorString(e));
+  return RT_OK;
+}
+
+int rt_eval_perlin_gradient(rt_ctx* c, const int32_t* ixy, size_t n, float* gxy) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (n == 0) return RT_OK;
+  if (!ixy || !gxy) return fail(RT_ERR_INVALID, "null point or result pointer");
+  if (n > ((size_t)1 << 28)) return fail(RT_ERR_INVALID, "too many points");
+  dev_buf<int2> in;
+  dev_buf<float2> out;
+  hipError_t e = in.resize(n);
+  if (e == hipSuccess) e = out.resize(n);
+  if (e == hipSuccess) e = hipMemcpyAsync(in.p, ixy, n * sizeof(int2), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    rt_eval_gradient_kernel<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(in.p, n, out.p);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(gxy, out.p, n * sizeof(float2), hipMemcpyDeviceToHost, c->stream);
+  const hipError_t s = hipStreamSynchronize(c->stream);
+  in.release();
+  out.release();
+  if (e == hipSuccess) e = s;
+  if (e != hipSuccess) return fail(RT_ERR_DEVICE, "rt_eval_perlin_gradient: %s", hipGetErrorString(e));
   return RT_OK;
 }
 

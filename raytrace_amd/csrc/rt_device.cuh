@@ -123,9 +123,6 @@ RT_DEV f3 random_unit_vector(uint32_t& a, lane_counters& k) {
     p = mk3(x, y, z);
     lensq = dot3(p, p);
     RT_COUNT(k, unit_tries, 1);
-#ifdef RT_ABL_ONE_TRY  // timing experiments only: wrong results
-    break;
-#endif
     if (0.0f < lensq && lensq <= 1.0f) break;
     i += 1u;
   }
@@ -142,9 +139,6 @@ RT_DEV f3 random_unit_disk(uint32_t& a, lane_counters& k) {
     float y = rng_float<RNG>(a);
     float lensq = (x * x + y * y) + 0.0f * 0.0f;
     RT_COUNT(k, disk_tries, 1);
-#ifdef RT_ABL_ONE_TRY
-    return mk3(x, y, 0.0f);
-#endif
     if (lensq <= 1.0f) return mk3(x, y, 0.0f);
     i += 1u;
   }
@@ -222,11 +216,18 @@ RT_DEV float perlin_dot(float gx, float gy, int ix, int iy, float x, float y) { 
 
 RT_DEV float perlin_lerp(float a0, float a1, float w) { return (a1 - a0) * w + a0; }  // perlin.h:11-16
 
+// (int)floor(v) of perlin.h:61-63.  Beyond the int range (and for NaN) C++ leaves the conversion undefined; the x86
+// hosts the reference runs on give 0x80000000 there, gfx950's own conversion saturates: the host's value is kept.
+RT_DEV int perlin_cell(float v) {
+  const float f = floorf(v);
+  return fabsf(f) < 2147483648.0f ? (int)f : (int)0x80000000;
+}
+
 RT_DEV float perlin2(float x, float y, perlin_table tab) {  // perlin.h:59-85
-  int x0 = (int)floorf(x);
-  int x1 = x0 + 1;
-  int y0 = (int)floorf(y);
-  int y1 = y0 + 1;
+  int x0 = perlin_cell(x);
+  int x1 = (int)((unsigned)x0 + 1u);
+  int y0 = perlin_cell(y);
+  int y1 = (int)((unsigned)y0 + 1u);
   float sx = x - (float)x0;
   float sy = y - (float)y0;
   float2 g00, g10, g01, g11;
@@ -284,14 +285,6 @@ struct hit_rec {
 template <int RNG, bool COUNTED>
 RT_DEV bool shade_hit(const hit_rec& h, int type, float param1, f3 m_albedo, perlin_table noise, f3& dir, f3& albedo,
                       uint32_t& rng, lane_counters& k) {
-#ifdef RT_ABL_LAMBERT_ONLY  // timing experiments only: wrong results
-  type = RT_MAT_LAMBERTIAN;
-#endif
-#ifdef RT_ABL_NO_SHADE
-  dir = h.normal + mk3(0.3f, 0.2f, 0.1f);
-  albedo = albedo * m_albedo;
-  return true;
-#endif
   const bool diffuse = type == RT_MAT_LAMBERTIAN || type == RT_MAT_PERLIN_LAMBERTIAN;
   const bool metal = type == RT_MAT_METALLIC;
   f3 ruv = mk3(0.0f, 0.0f, 0.0f);

@@ -766,6 +766,20 @@ __global__ __launch_bounds__(256) void rt_perlin_table_kernel(float2* grad, int 
   grad[i] = make_float2(gx, gy);
 }
 
+// perlin(x, y) of perlin.h:59-85 for a list of points, and randomGradient of perlin.h:31-43 for a list of
+// lattice points: the device functions the noise-textured material uses, callable on their own.
+__global__ __launch_bounds__(256) void rt_eval_perlin_kernel(const float2* xy, size_t n, perlin_table tab, float* value) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) value[i] = perlin2(xy[i].x, xy[i].y, tab);
+}
+__global__ __launch_bounds__(256) void rt_eval_gradient_kernel(const int2* ixy, size_t n, float2* g) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float gx, gy;
+  perlin_gradient(ixy[i].x, ixy[i].y, gx, gy);
+  g[i] = make_float2(gx, gy);
+}
+
 // End of the shader's main (fs:135-140) and the RGB8 store: mean over the
 // samples, gamma 1/2.2, clamp, round to nearest.
 __global__ __launch_bounds__(256) void rt_resolve_kernel(const float* accum, size_t n_values, float inv_samples,

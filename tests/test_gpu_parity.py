@@ -143,9 +143,9 @@ def test_perlin_scene_small(renderer):
     p = rt.make_params(cam, 128, 72, 4, rng_mode=rt.RNG_COUNTER)
     lin, q, c, olin, oq, oc = _render_both(renderer, scene, p, rt.ACCEL_LBVH)
     assert c["perlin"] == oc["perlin"] and c["perlin"] > 0
-    # cos/sin of the gradient angle are evaluated in double on both sides by
-    # different libraries; a last-bit difference of one gradient is allowed.
-    np.testing.assert_allclose(lin, olin, rtol=2e-6, atol=1e-7)
+    # cos / sin of the gradient angle are evaluated in double on both sides and narrowed: the device function gives
+    # the bits of the reference's own perlin.h on every stored vector (test_gpu_edges.py), and so does the frame
+    assert_same_f32(lin, olin, "linear radiance")
 
 
 def test_tiles_and_sample_ranges_compose(renderer):
