@@ -39,8 +39,9 @@ struct search_traits {
   static constexpr int waves = lds ? 16 : 4;       // waves per workgroup
   static constexpr int threads = waves * 64;
   static constexpr int stack = lds ? 16 : 8;       // entries per lane kept in LDS
-  // per wave: one word per entry and lane, and one more row, the sink of stores that must not land
-  static constexpr int stack_words = !tree ? 0 : (stack + 1) * 64;
+  // per wave: one word per entry and lane; above the last row, three rows of slack for trees in LDS (a node step
+  // stores three keys above the top whatever it pushes), one row for the others (the sink of stores that do not fit)
+  static constexpr int stack_words = !tree ? 0 : (stack + (lds ? 3 : 1)) * 64;
   // trees read from HBM pass their nodes through a per-wave staging area in LDS (stage_nodes)
   static constexpr bool staged = tree && !lds;
   static constexpr int stage_bytes = staged ? RT_STAGE_BYTES : 0;

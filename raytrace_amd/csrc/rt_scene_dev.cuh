@@ -460,6 +460,16 @@ struct leaf_queue<false> {
   }
 };
 
+// The reference of the lowest child named in a mask of children (three selects, not a branch per child).
+RT_DEV int pick_ref(int4 ref, unsigned mask) {
+  const int ch = __builtin_ctz(mask | 8u);
+  int r = ref.x;
+  r = ch == 1 ? ref.y : r;
+  r = ch == 2 ? ref.z : r;
+  r = ch == 3 ? ref.w : r;
+  return r;
+}
+
 // A closest-hit search that can be advanced one node at a time, so that a wave
 // can interleave the traversal steps of some lanes with other work of others.
 //   begin()  exact tests of the spheres kept out of the tree, per-ray constants;
@@ -581,63 +591,79 @@ struct tree_search {
       ok[ch] = SELECT ? tn[ch] <= tf[ch] : bool((tn[ch] <= tf[ch]) & (refs[ch] != RT_REF_EMPTY));
       RT_COUNT(k, node_tests, refs[ch] != RT_REF_EMPTY ? 1u : 0u);
       if (LEAF_INLINE) {
-        leaf_mask |= ((ok[ch] ? 1u : 0u) & ((uint32_t)refs[ch] >> 31)) << ch;  // arithmetic, not a branch per child
+        leaf_mask |= (ok[ch] & (refs[ch] < 0)) ? (1u << ch) : 0u;  // a select on combined lane masks, not a branch per child
       } else if (ok[ch] && refs[ch] < 0) {
         lq.push(~refs[ch]);
       }
     }
-    // LDS-resident scenes test the leaves here and now (an exact hit shortens the
-    // ray for the boxes below, and a leaf costs less than another trip round the
-    // wave's loop); scenes read from HBM queue them for a leaf step, so that the
-    // wave waits for leaf records once per step, not once per node
-    while (LEAF_INLINE && leaf_mask) {
-      const int ch = __builtin_ctz(leaf_mask);
-      leaf_mask &= leaf_mask - 1;
-      int r = refs[0];  // three selects, not a branch per child
-      r = ch == 1 ? refs[1] : r;
-      r = ch == 2 ? refs[2] : r;
-      r = ch == 3 ? refs[3] : r;
-      const int pos = ~r;
-      consider_sphere<COUNTED>(sv.leaf_sph[pos], sv.leaf_idx[pos], o, d, a, c, k);
+    // LDS-resident scenes test the leaves here and now (an exact hit shortens the ray for what is popped later, and a
+    // leaf costs less than another trip round the wave's loop); scenes read from HBM queue them for a leaf step, so
+    // that the wave waits for leaf records once per step, not once per node.  The record of the first leaf is
+    // asked for before the children are sorted and pushed, so that the read is under way while that happens.
+#define leaf_ref(m) pick_ref(ref, (m))
+    int pos0 = 0;
+    float4 sph0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (LEAF_INLINE) {
+      pos0 = leaf_mask ? ~leaf_ref(leaf_mask) : 0;
+      sph0 = sv.leaf_sph[pos0];
     }
+    // Children worth a visit, as stack keys; zero = none.  Sorted descending, the valid keys come first, farthest
+    // first, and the nearest valid one is last.
     uint32_t key[4];
 #pragma unroll
-    for (int ch = 0; ch < 4; ch++) {
-      const bool go = ok[ch] && refs[ch] >= 0 && tn[ch] <= c.best_t;
-      key[ch] = go ? stk.key(tn[ch], refs[ch]) : 0xFFFFFFFFu;
-    }
-    // sort the four keys ascending (invalid = all ones sinks to the end)
+    for (int ch = 0; ch < 4; ch++) key[ch] = (ok[ch] & (refs[ch] >= 0)) ? stk.key(tn[ch], refs[ch]) : 0u;
 #define RT_CE(i, j)                               \
   do {                                            \
-    const uint32_t lo_ = min(key[i], key[j]);     \
-    key[j] = max(key[i], key[j]);                 \
-    key[i] = lo_;                                 \
+    const uint32_t hi_ = max(key[i], key[j]);     \
+    key[j] = min(key[i], key[j]);                 \
+    key[i] = hi_;                                 \
   } while (0)
     RT_CE(0, 1); RT_CE(2, 3); RT_CE(0, 2); RT_CE(1, 3); RT_CE(1, 2);
 #undef RT_CE
-    // The nearest child is next; the others go on the stack, farthest first, so
-    // that the nearest of them is popped first.  Three unconditional stores:
-    // key[e] of cnt valid keys belongs at sp + cnt-1-e; the keys that are not
-    // valid, and those that do not fit into the LDS rows, go to row STACK, which
-    // nobody reads.  Trees read from HBM keep the entries beyond the LDS rows in
+    // The nearest child is next; the others go on the stack, farthest first, so that the nearest of them is popped
+    // first.  key[e] of cnt valid keys belongs at row sp + e for e < cnt - 1: key[0..2] are stored at rows sp .. sp + 2
+    // whatever cnt is — what lands beyond the new top is never read — so the stores need no index arithmetic (trees
+    // in LDS keep three rows of slack above the last row).  Trees read from HBM keep the entries beyond the LDS rows in
     // their overflow buffer; for trees in LDS an overflow sends the ray to the scan.
-    const int cnt = (key[0] != 0xFFFFFFFFu ? 1 : 0) + (key[1] != 0xFFFFFFFFu ? 1 : 0) + (key[2] != 0xFFFFFFFFu ? 1 : 0) +
-                    (key[3] != 0xFFFFFFFFu ? 1 : 0);
+    const uint32_t pushed = min(key[1], 1u) + min(key[2], 1u) + min(key[3], 1u);  // valid keys but one (every valid key is > 1)
+    if (PACKED) {
+      uint32_t* top = stk.col + sp * 64;
+      top[0] = key[0];
+      top[64] = key[1];
+      top[128] = key[2];
+      sp += (int)pushed;
+      c.redo = c.redo | (sp > STACK);
+      sp = min(sp, STACK);
+    } else {
 #pragma unroll
-    for (int e = 1; e <= 3; e++) {
-      const int want = sp + cnt - 1 - e;
-      const int row = e < cnt ? min(want, STACK) : STACK;
-      stk.col[row * 64] = key[e];
-      if (!PACKED && e < cnt && want >= STACK) {
-        if (want - STACK < sv.ovf_cap) sv.ovf_col[(size_t)(want - STACK) * 64] = key[e];
-        else c.redo = true;
+      for (int e = 0; e < 3; e++) {
+        const int row = sp + e;
+        stk.col[min(row, STACK) * 64] = key[e];  // row STACK: the sink of what does not fit the LDS rows
+        if (e < (int)pushed && row >= STACK) {
+          if (row - STACK < sv.ovf_cap) sv.ovf_col[(size_t)(row - STACK) * 64] = key[e];
+          else c.redo = true;
+        }
       }
+      const int grown = sp + (int)pushed, room = STACK + sv.ovf_cap;
+      sp = min(grown, room);
     }
-    const int grown = sp + max(cnt - 1, 0), room = PACKED ? STACK : STACK + sv.ovf_cap;
-    c.redo = c.redo || grown > room;
-    sp = min(grown, room);
-    if (key[0] != 0xFFFFFFFFu) {
-      cur = stk.key_ref(key[0]);
+    uint32_t next = key[0];  // the last valid key
+    next = key[1] ? key[1] : next;
+    next = key[2] ? key[2] : next;
+    next = key[3] ? key[3] : next;
+    if (LEAF_INLINE && leaf_mask) {
+      consider_sphere<COUNTED>(sph0, sv.leaf_idx[pos0], o, d, a, c, k);
+      leaf_mask &= leaf_mask - 1;
+      while (leaf_mask) {
+        const int pos = ~leaf_ref(leaf_mask);
+        leaf_mask &= leaf_mask - 1;
+        consider_sphere<COUNTED>(sv.leaf_sph[pos], sv.leaf_idx[pos], o, d, a, c, k);
+      }
+      if (!(stk.key_tn(next) <= c.best_t)) next = 0u;  // a leaf hit nearer than the nearest child: the stack decides
+    }
+#undef leaf_ref
+    if (next != 0u) {
+      cur = stk.key_ref(next);
       return;
     }
     cur = -1;
