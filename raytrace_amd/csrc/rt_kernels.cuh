@@ -207,10 +207,15 @@ struct searcher {
     if (T::tree) return ts.begin(sc, sv, o, d, k);
     ts.o = o;
     ts.d = d;
-    ts.c.redo = true;  // finish() runs the scan
+    ts.cur = -1;
+    ts.c.give_up();  // finish() runs the scan
     return false;
   }
   static constexpr bool leaf_steps = T::tree && (!T::lds || RT_LDS_LEAF_STEPS);  // leaves wait for a step of their own
+  RT_DEV void reset() {  // no search under way
+    ts.cur = -1;
+    if (!ts.LEAF_INLINE) ts.lq.clear();
+  }
   RT_DEV bool node_ready() const { return T::tree && ts.node_ready(); }
   RT_DEV bool has_leaf() const { return T::tree && ts.has_leaf(); }
   RT_DEV bool active() const { return T::tree && ts.active(); }
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
   bool have = false;        // this lane owns a pixel
   bool alive = false;       // a path of that pixel is in flight
   bool pending = false;     // a finished search waits to be shaded
-  bool in_trav = false;     // the search needs more steps
+  srch.reset();             // (a lane is traversing while its search is active: no flag of its own)
   bool exhausted = P.sample_end <= P.sample_begin;
   int x = 0, y = 0, s = 0, s_end = P.sample_end;
   uint32_t pixel = 0, rect_pixel = 0, rng = 0, count = 0, pixel_segments = 0, split_row = RT_JOB_WHOLE;
@@ -371,13 +376,15 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
 
   RT_CLK_DECL
   while (true) {
-    const unsigned long long m_trav = __ballot(in_trav);
-    const unsigned long long m_ready = __ballot(!in_trav && !exhausted);
-    if ((m_trav | m_ready) == 0ull) break;
-    const bool path_phase = m_trav == 0ull || __popcll(m_ready) >= A.vote;
-    RT_CLK_START();
-    if (!path_phase) {  // `pending` (set at begin) marks the result as unread
-      const bool node_lane = in_trav && srch.node_ready(), leaf_lane = in_trav && srch.has_leaf();
+    // Traversal steps for the lanes that are traversing, until enough lanes are ready for the path phase to be worth
+    // a full wave (or no lane is traversing).  Which lanes have run out of work changes in the path phase only.
+    const unsigned long long m_live = __ballot(!exhausted);
+    if (m_live == 0ull) break;
+    while (search_traits<SEARCH>::tree) {  // `pending` (set at begin) marks the result as unread
+      const unsigned long long m_trav = __ballot(srch.active());
+      if (m_trav == 0ull || __popcll(m_live & ~m_trav) >= A.vote) break;
+      RT_CLK_START();
+      const bool node_lane = srch.node_ready(), leaf_lane = srch.has_leaf();
       if (srch.leaf_steps && (__ballot(node_lane) == 0ull || __popcll(__ballot(leaf_lane)) >= A.leaf_vote)) {
         RT_COUNT(k, leaf_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
         RT_COUNT(k, leaf_lane_steps, leaf_lane ? 1u : 0u);
@@ -389,12 +396,11 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
         if (search_traits<SEARCH>::staged) staged = stage_nodes(sv.nodes, node_lane ? srch.node_wanted() : -1, stage);
         if (node_lane) srch.step_node(sv, stack_col, staged, k);
       }
-      if (in_trav) in_trav = srch.active();
       RT_CLK_STOP(0);
-      continue;
     }
+    RT_CLK_START();
     RT_COUNT(k, path_wave_phases, (threadIdx.x & 63) == 0 ? 1u : 0u);
-    const bool ready = !(in_trav || exhausted);  // only ready lanes take the path phase
+    const bool ready = !(srch.active() || exhausted);  // only ready lanes take the path phase
     RT_COUNT(k, path_lane_phases, ready ? 1u : 0u);
 
     bool start_segment = false;
@@ -536,7 +542,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
     if (start_segment) {
       RT_COUNT(k, segments, 1);
       pixel_segments++;
-      in_trav = srch.begin(sc, sv, srch.ts.o, srch.ts.d, k);
+      srch.begin(sc, sv, srch.ts.o, srch.ts.d, k);
       pending = true;
     }
     RT_CLK_STOP(5);
@@ -690,17 +696,18 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
   lane_counters k = {};
   searcher<SEARCH, COUNTED> srch;
   srch.ref_mask = sc.ref_mask;
-  bool pending = false, in_trav = false, exhausted = false;
+  bool pending = false, exhausted = false;
+  srch.reset();
   size_t ray = 0;
   unsigned long long pool_next = 0, pool_end = 0;  // the wave's share of the ray queue
 
   while (true) {
-    const unsigned long long m_trav = __ballot(in_trav);
-    const unsigned long long m_ready = __ballot(!in_trav && !exhausted);
-    if ((m_trav | m_ready) == 0ull) break;
-    const bool path_phase = m_trav == 0ull || __popcll(m_ready) >= A.vote;
-    if (!path_phase) {
-      const bool node_lane = in_trav && srch.node_ready(), leaf_lane = in_trav && srch.has_leaf();
+    const unsigned long long m_live = __ballot(!exhausted);
+    if (m_live == 0ull) break;
+    while (search_traits<SEARCH>::tree) {
+      const unsigned long long m_trav = __ballot(srch.active());
+      if (m_trav == 0ull || __popcll(m_live & ~m_trav) >= A.vote) break;
+      const bool node_lane = srch.node_ready(), leaf_lane = srch.has_leaf();
       if (srch.leaf_steps && (__ballot(node_lane) == 0ull || __popcll(__ballot(leaf_lane)) >= A.leaf_vote)) {
         RT_COUNT(k, leaf_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
         RT_COUNT(k, leaf_lane_steps, leaf_lane ? 1u : 0u);
@@ -712,11 +719,9 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
         if (search_traits<SEARCH>::staged) staged = stage_nodes(sv.nodes, node_lane ? srch.node_wanted() : -1, stage);
         if (node_lane) srch.step_node(sv, stack_col, staged, k);
       }
-      if (in_trav) in_trav = srch.active();
-      continue;
     }
     RT_COUNT(k, path_wave_phases, (threadIdx.x & 63) == 0 ? 1u : 0u);
-    const bool ready = !(in_trav || exhausted);
+    const bool ready = !(srch.active() || exhausted);
     const unsigned long long next_ray = take_items<unsigned long long, 256u>(ready, A.queue, pool_next, pool_end);
     if (!ready) continue;
     RT_COUNT(k, path_lane_phases, 1);
@@ -751,7 +756,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       const f3 o = mk3(A.o_xyz[3 * ray], A.o_xyz[3 * ray + 1], A.o_xyz[3 * ray + 2]);
       const f3 d = mk3(A.d_xyz[3 * ray], A.d_xyz[3 * ray + 1], A.d_xyz[3 * ray + 2]);
       RT_COUNT(k, segments, 1);
-      in_trav = srch.begin(sc, sv, o, d, k);
+      srch.begin(sc, sv, o, d, k);
       pending = true;
     }
   }

@@ -233,10 +233,19 @@ RT_DEV void hit_linear(const float4* sph, int n, f3 o, f3 d, float& t_out, int& 
 #define RT_PAD_LIN 1.0e-6f
 #define RT_T_FLOOR 0.000999f
 
+// The running closest hit.  best_i: upload index, -1 while there is none, RT_REDO once the search has met a case only
+// the scan can decide; best_t is then -infinity, so that no box is worth a visit and no root is accepted any more and
+// the search winds down by itself.  (Lane state kept in these two registers: a flag of its own would be a lane mask
+// the compiler merges at every join of the wave's loop.)
+#define RT_REDO (-2)
 struct trav_candidate {
   float best_t;
   int best_i;
-  bool redo;
+  RT_DEV void give_up() {
+    best_t = -__builtin_inff();
+    best_i = RT_REDO;
+  }
+  RT_DEV bool redo() const { return best_i == RT_REDO; }
 };
 
 // Exact test of one sphere against the running closest hit.
@@ -247,7 +256,7 @@ RT_DEV void consider_sphere(float4 s, int upload_index, f3 o, f3 d, float a, tra
   sphere_disc(s.x, s.y, s.z, s.w, o, d, a, h, disc);
   if (disc >= 0.0f) {
     float t = sphere_roots<COUNTED>(h, disc, a, k);
-    if (t != t || t == 0.001f) c.redo = true;
+    if (t != t || t == 0.001f) c.give_up();
     if (t > 0.001f && (t < c.best_t || (t == c.best_t && upload_index < c.best_i))) {
       c.best_t = t;
       c.best_i = upload_index;
@@ -501,12 +510,11 @@ struct tree_search {
     a = dot3(d, d);
     c.best_t = __builtin_inff();
     c.best_i = -1;
-    c.redo = false;
     sp = 0;
     cur = -1;
     if (!LEAF_INLINE) lq.clear();
     if (!(a > 0.0f) || !(a < __builtin_inff())) {  // zero, NaN or overflowing direction: the scan decides
-      c.redo = true;
+      c.give_up();
       return false;
     }
     // spheres kept out of the tree: exact tests, wave-uniform index
@@ -523,7 +531,7 @@ struct tree_search {
       // away along a nearly flat direction overflows them): the scan decides such a ray
       const float sum = ((fabsf(sl.k_lo.x) + fabsf(sl.k_lo.y)) + fabsf(sl.k_lo.z)) + ((fabsf(sl.k_hi.x) + fabsf(sl.k_hi.y)) + fabsf(sl.k_hi.z));
       if (!(sum < __builtin_inff())) {
-        c.redo = true;
+        c.give_up();
         return false;
       }
     }
@@ -632,8 +640,11 @@ struct tree_search {
       top[64] = key[1];
       top[128] = key[2];
       sp += (int)pushed;
-      c.redo = c.redo | (sp > STACK);
-      sp = min(sp, STACK);
+      if (sp > STACK) {  // (rare: a chain deeper than the rows)
+        c.give_up();
+        sp = 0;
+        key[0] = key[1] = key[2] = key[3] = 0u;
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < 3; e++) {
@@ -641,7 +652,7 @@ struct tree_search {
         stk.col[min(row, STACK) * 64] = key[e];  // row STACK: the sink of what does not fit the LDS rows
         if (e < (int)pushed && row >= STACK) {
           if (row - STACK < sv.ovf_cap) sv.ovf_col[(size_t)(row - STACK) * 64] = key[e];
-          else c.redo = true;
+          else c.give_up();
         }
       }
       const int grown = sp + (int)pushed, room = STACK + sv.ovf_cap;
@@ -681,7 +692,7 @@ struct tree_search {
   }
 
   RT_DEV void finish(const scene_dev& sc, const scene_view& sv, float& t_out, int& i_out, lane_counters& k) {
-    if (c.redo) {
+    if (c.redo()) {
       hit_linear<COUNTED>(sv.scan_sph, sc.n_spheres, o, d, t_out, i_out, k);
       return;
     }
