@@ -78,6 +78,11 @@ struct dev_buf {
 constexpr size_t kSplitBudgetBytes = (size_t)32 << 30;
 // The same for the probe pass in sweeps (every pixel's probe samples): beyond this the probe runs unsplit.
 constexpr size_t kProbeBudgetBytes = (size_t)4 << 30;
+// A stored sample is one aligned 16-byte record (r, g, b, unused): one store request per lane, whole 64-byte lines per
+// group of four neighbouring rows, where three separate words per sample were written as partial lines (measured:
+// 3.1 bytes written per byte of payload).
+constexpr size_t kSampleFloats = 4;
+inline size_t stored_samples(int n) { return (size_t)n; }
 // Largest dynamic LDS a launch may ask for (the CU has 160 KiB).
 constexpr size_t kMaxLdsBytes = 160 * 1024;
 // The linear scan stages its sphere records in LDS up to this many bytes.
@@ -970,19 +975,19 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   scratch_budgets(c, split_budget, probe_budget);
   bool whole_in_sweeps = !two_pass && two_pass_enabled() && p->rng_mode == RT_RNG_COUNTER && probe_sweeps() > 1 &&
                          n_samples >= 2 && n_rect >= 16384 &&
-                         n_rect * (size_t)n_samples * 3 * sizeof(float) <= probe_budget;
+                         n_rect * stored_samples(n_samples) * kSampleFloats * sizeof(float) <= probe_budget;
   // (a store that cannot be had costs speed, never the frame: the plain schedules below need none)
-  if (whole_in_sweeps && c->probe_samples.fit(n_rect * (size_t)n_samples * 3) != hipSuccess) whole_in_sweeps = false;
+  if (whole_in_sweeps && c->probe_samples.fit(n_rect * stored_samples(n_samples) * kSampleFloats) != hipSuccess) whole_in_sweeps = false;
   if (whole_in_sweeps) {
     render_args sw = a;
     sw.pass = 3;
     sw.sweeps = probe_sweeps() < n_samples ? probe_sweeps() : n_samples;
-    sw.split_samples = c->probe_samples.p;
+    sw.split_samples = reinterpret_cast<float4*>(c->probe_samples.p);
     sw.main_samples = n_samples;
     e = launch(sw, p);
     if (e == hipSuccess) {
       rt_probe_sum_kernel<<<(unsigned)((n_rect + 255) / 256), 256, 0, c->stream>>>(
-          (uint32_t)n_rect, c->probe_samples.p, n_samples, p->tile_x0, p->tile_y0, tw, p->width, c->accum(), nullptr, nullptr);
+          (uint32_t)n_rect, reinterpret_cast<const float4*>(c->probe_samples.p), n_samples, p->tile_x0, p->tile_y0, tw, p->width, c->accum(), nullptr, nullptr);
       e = hipGetLastError();
     }
   } else if (!two_pass) {
@@ -1007,8 +1012,8 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
     // Counter RNG: the probe runs in sweeps (see render_args), its samples in a buffer of their own.
     bool swept = p->rng_mode == RT_RNG_COUNTER && probe_sweeps() > 1;
     int n_probe = probe_samples(n_samples, swept);
-    if (swept && (n_rect * (size_t)n_probe * 3 * sizeof(float) > probe_budget ||
-                  c->probe_samples.fit(n_rect * (size_t)n_probe * 3) != hipSuccess)) {
+    if (swept && (n_rect * stored_samples(n_probe) * kSampleFloats * sizeof(float) > probe_budget ||
+                  c->probe_samples.fit(n_rect * stored_samples(n_probe) * kSampleFloats) != hipSuccess)) {
       swept = false;
       n_probe = probe_samples(n_samples, false);
     }
@@ -1018,13 +1023,13 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       HIP_TRY(hipMemsetAsync(c->carry_cost.p, 0, n_rect * sizeof(uint32_t), c->stream));
       probe.pass = 3;
       probe.sweeps = sweeps;
-      probe.split_samples = c->probe_samples.p;
+      probe.split_samples = reinterpret_cast<float4*>(c->probe_samples.p);
       probe.main_samples = n_probe;
     }
     e = launch(probe, p);
     if (e == hipSuccess && swept) {
       rt_probe_sum_kernel<<<(unsigned)((n_rect + 255) / 256), 256, 0, c->stream>>>(
-          (uint32_t)n_rect, c->probe_samples.p, n_probe, p->tile_x0, p->tile_y0, tw, p->width, c->accum(), c->carry_colour.p,
+          (uint32_t)n_rect, reinterpret_cast<const float4*>(c->probe_samples.p), n_probe, p->tile_x0, p->tile_y0, tw, p->width, c->accum(), c->carry_colour.p,
           c->carry_rng.p);
       e = hipGetLastError();
       probe.pass = 1;  // what follows copies `probe` for the main pass
@@ -1046,7 +1051,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       const uint32_t n = (uint32_t)n_rect;
       // a job should be a small fraction (1 / split_fineness()) of a lane's fair share of the frame
       const uint32_t lanes = (uint32_t)c->n_cu * 1024u * (uint32_t)split_fineness();
-      size_t want = split_budget / ((size_t)main_samples * 3 * sizeof(float));
+      size_t want = split_budget / (stored_samples(main_samples) * kSampleFloats * sizeof(float));
       // (only where rays walk a tree worth the name: the scan and a tree of a few spheres gain nothing from
       // neighbouring rays, and every sample stored and read back costs them 24 bytes of traffic — the two-sphere
       // noise scene ran 18 % slower with six jobs per pixel)
@@ -1063,7 +1068,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       uint32_t max_split = (uint32_t)(want > row_cap ? row_cap : want);
       if (p->rng_mode != RT_RNG_COUNTER) max_split = 0;
       // the store of the cut pixels' samples: when the device cannot give it, fewer pixels are cut, in the end none
-      while (max_split > 0 && c->split_samples.fit((size_t)max_split * (size_t)main_samples * 3) != hipSuccess) max_split /= 2;
+      while (max_split > 0 && c->split_samples.fit((size_t)max_split * stored_samples(main_samples) * kSampleFloats) != hipSuccess) max_split /= 2;
       const int splittable = max_split > 0 ? 1 : 0;
       HIP_TRY(c->plan_parts.resize(n));
       HIP_TRY(c->plan_first.resize(n));
@@ -1090,14 +1095,14 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       mainp.p.sample_end = p->sample_end;
       mainp.jobs = c->plan_jobs.p;
       mainp.n_jobs = c->plan_counts.p;
-      mainp.split_samples = c->split_samples.p;
+      mainp.split_samples = reinterpret_cast<float4*>(c->split_samples.p);
       mainp.main_samples = main_samples;
       mainp.split_rows = n < max_split ? n : max_split;
       e = launch(mainp, p);
       if (e == hipSuccess && splittable) {
         const uint32_t cand = n < max_split ? n : max_split;
         rt_sum_split_kernel<<<(cand + 255) / 256, 256, 0, c->stream>>>(c->order_idx.p, c->plan_parts.p, cand, c->carry_colour.p,
-                                                                      c->split_samples.p, main_samples, cand, p->tile_x0, p->tile_y0,
+                                                                      reinterpret_cast<const float4*>(c->split_samples.p), main_samples, cand, p->tile_x0, p->tile_y0,
                                                                       tw, p->width, c->accum());
         e = hipGetLastError();
       }

@@ -106,13 +106,19 @@ struct render_args {
   // keeps the pixel's sum bit-identical to a sequential evaluation.
   const uint4* jobs;           // (rect pixel, first sample, end sample, split row or RT_JOB_WHOLE)
   const uint32_t* n_jobs;      // how many there are (computed on the device)
-  float* split_samples;        // split row r, sample s of the main pass: 3 floats at (s * split_rows + r) * 3 (sample-major:
-                               // the jobs a wave holds are neighbours in the order, and the sum reads whole planes)
+  float4* split_samples;       // split row r, sample s of the main pass: one 16-byte record (r, g, b, -) at sample_slot(s, r, rows)
   int main_samples;            // samples per pixel of the main pass
   uint32_t split_rows;         // rows of split_samples
 };
 
 #define RT_JOB_WHOLE 0xFFFFFFFFu
+
+// Where the record of sample s (counted from the first sample of the pass) of row r lies in a per-sample store of
+// `rows` rows: sample-major, plane s holds that sample of every row, so that lanes holding neighbouring rows write next
+// to each other and the kernels that add the samples up read whole planes.  (Measured and not kept: groups of four
+// samples of a row in one 64-byte line, written by one lane over time — the L2 does not hold the line until it is
+// complete, 22 GB written per C2 frame against 17 GB.)
+RT_DEV size_t sample_slot(uint32_t s, size_t r, size_t rows) { return (size_t)s * rows + r; }
 
 template <bool COUNTED>
 RT_DEV void flush_counters(unsigned long long* g, const lane_counters& k) {
@@ -367,10 +373,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       // sample-major: plane s holds that sample of every row (split pixels of the main pass; every pixel of a pass
       // in sweeps), so that lanes holding neighbouring rows write next to each other
       const size_t rows = A.pass == 3 ? (size_t)tw * (size_t)th : (size_t)A.split_rows;
-      float* dst = A.split_samples + ((size_t)(s - P.sample_begin) * rows + (size_t)split_row) * 3;
-      dst[0] = alb.x;
-      dst[1] = alb.y;
-      dst[2] = alb.z;
+      A.split_samples[sample_slot((uint32_t)(s - P.sample_begin), (size_t)split_row, rows)] = make_float4(alb.x, alb.y, alb.z, 0.0f);
     }
   };
 
@@ -611,15 +614,15 @@ __global__ __launch_bounds__(256) void rt_plan_jobs_kernel(const uint32_t* order
 // Pixels that were cut into several jobs: the samples are added in sample order onto the sum the
 // probe pass carried, exactly as one lane would have added them.
 __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order, const uint32_t* parts, uint32_t n_candidates,
-                                                          const float* carry_colour, const float* split_samples, int samples,
+                                                          const float* carry_colour, const float4* split_samples, int samples,
                                                           uint32_t n_rows, int tile_x0, int tile_y0, int tile_w, int width, float* accum) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_candidates || parts[i] <= 1u) return;
   const uint32_t rect_pixel = order[i];
   f3 colour = mk3(carry_colour[3 * (size_t)rect_pixel], carry_colour[3 * (size_t)rect_pixel + 1], carry_colour[3 * (size_t)rect_pixel + 2]);
-  for (int s = 0; s < samples; s++) {  // sample-major buffer: consecutive threads read consecutive rows
-    const float* src = split_samples + ((size_t)s * n_rows + i) * 3;
-    colour = colour + mk3(src[0], src[1], src[2]);
+  for (int s = 0; s < samples; s++) {  // consecutive threads read consecutive lines of a group's plane
+    const float4 v = split_samples[sample_slot((uint32_t)s, i, n_rows)];
+    colour = colour + mk3(v.x, v.y, v.z);
   }
   const int x = tile_x0 + (int)(rect_pixel % (uint32_t)tile_w), y = tile_y0 + (int)(rect_pixel / (uint32_t)tile_w);
   float* dst = accum + 3 * ((size_t)y * (size_t)width + (size_t)x);
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order
 // sample ranges left in the image, exactly as one lane would have added them.  The sum goes to the
 // carry arrays (a probe: the main pass continues from it) or, with carry_colour null, back into the
 // image (a frame rendered in sweeps as a whole).
-__global__ __launch_bounds__(256) void rt_probe_sum_kernel(uint32_t n_rect, const float* probe_samples, int n_probe, int tile_x0,
+__global__ __launch_bounds__(256) void rt_probe_sum_kernel(uint32_t n_rect, const float4* probe_samples, int n_probe, int tile_x0,
                                                           int tile_y0, int tile_w, int width, float* accum,
                                                           float* carry_colour, uint32_t* carry_rng) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -640,9 +643,9 @@ __global__ __launch_bounds__(256) void rt_probe_sum_kernel(uint32_t n_rect, cons
   const int x = tile_x0 + (int)(i % (uint32_t)tile_w), y = tile_y0 + (int)(i / (uint32_t)tile_w);
   float* base = accum + 3 * ((size_t)y * (size_t)width + (size_t)x);
   f3 colour = mk3(base[0], base[1], base[2]);
-  for (int s = 0; s < n_probe; s++) {  // sample-major buffer: consecutive threads read consecutive pixels
-    const float* src = probe_samples + ((size_t)s * n_rect + i) * 3;
-    colour = colour + mk3(src[0], src[1], src[2]);
+  for (int s = 0; s < n_probe; s++) {  // consecutive threads read consecutive lines of a group's plane
+    const float4 v = probe_samples[sample_slot((uint32_t)s, i, n_rect)];
+    colour = colour + mk3(v.x, v.y, v.z);
   }
   float* dst = carry_colour ? carry_colour + 3 * (size_t)i : base;
   dst[0] = colour.x;

@@ -552,7 +552,7 @@ struct tree_search {
   // whole tree is in LDS).
   RT_DEV void step_node(const scene_view& sv, trav_stack<PACKED> stk, uint32_t staged, lane_counters& k) {
     const unsigned char* nd = rt_lds + staged;
-    if (PACKED) nd = reinterpret_cast<const unsigned char*>(sv.nodes) + (size_t)cur * RT_LDS_NODE_STRIDE;
+    if (PACKED) nd = reinterpret_cast<const unsigned char*>(sv.nodes) + __umul24((unsigned)cur, (unsigned)RT_LDS_NODE_STRIDE);  // (full-rate multiply)
     const int4 ref = PACKED ? reinterpret_cast<const int4*>(nd)[6]
                             : *reinterpret_cast<const int4*>(reinterpret_cast<const unsigned char*>(sv.nodes) + (size_t)cur * sizeof(bvh4_node) + 96);
     const int refs[4] = {ref.x, ref.y, ref.z, ref.w};
@@ -612,7 +612,10 @@ struct tree_search {
     int pos0 = 0;
     float4 sph0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (LEAF_INLINE) {
-      pos0 = leaf_mask ? ~leaf_ref(leaf_mask) : 0;
+      int first = -1;  // the reference of the lowest leaf among the children worth a visit: selects on the masks just formed
+#pragma unroll
+      for (int ch = 3; ch >= 0; ch--) first = (ok[ch] & (refs[ch] < 0)) ? refs[ch] : first;
+      pos0 = ~first;  // (no such leaf: position 0, read and not used)
       sph0 = sv.leaf_sph[pos0];
     }
     // Children worth a visit, as stack keys; zero = none.  Sorted descending, the valid keys come first, farthest
