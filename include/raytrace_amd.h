@@ -90,7 +90,12 @@ typedef struct rt_params {
   float defocus_angle;
   int32_t rng_mode;                /* RT_RNG_*                                              */
   uint32_t seed;                   /* RT_RNG_COUNTER key                                    */
-  uint32_t reserved0;
+  /* Interleaved shares of the tile (no counterpart in the reference; 0, 0 = the whole tile): the
+   * tile's rows are taken in strips of eight, and this call renders the strips whose number
+   * (from the top of the tile) is strip_index modulo strip_count.  The shares of strip_count
+   * calls (or GPUs) are disjoint, cover the tile, and cost about the same each, which row bands
+   * of a frame with sky above and spheres below do not.                                       */
+  uint16_t strip_count, strip_index;
   /* RT_RNG_XORSHIFT_REF only: width*height words, row y of the image at
    * [y*width, (y+1)*width): the bits of (tex.r + tex.g + tex.b) that the shader
    * reads at testFragment.fs:105-106.  Host pointer; NULL means all zero.  It is

@@ -504,6 +504,8 @@ int orc_render(const void* spheres_std140, int n_spheres, const void* materials_
   std::vector<Counters> ks((size_t)threads);
   auto work = [&](int tid) {
     for (int y = p->tile_y0 + tid; y < p->tile_y1; y += threads) {
+      // interleaved shares (rt_params.strip_count / strip_index): strips of eight rows from the top of the tile
+      if (p->strip_count != 0 && ((y - p->tile_y0) / 8) % p->strip_count != p->strip_index) continue;
       for (int x = p->tile_x0; x < p->tile_x1; x++) {
         float* dst = accum + 3 * ((size_t)y * (size_t)p->width + (size_t)x);
         const V3 c = pixel_sum(sc, *p, x, y, v3(dst[0], dst[1], dst[2]), ks[(size_t)tid]);

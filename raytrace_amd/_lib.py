@@ -28,7 +28,8 @@ class RtParams(ctypes.Structure):
         ("delta_u", c_float3), ("delta_v", c_float3), ("camera_origin", c_float3),
         ("viewport_top_left", c_float3), ("defocus_disk_u", c_float3), ("defocus_disk_v", c_float3),
         ("defocus_angle", ctypes.c_float),
-        ("rng_mode", ctypes.c_int32), ("seed", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
+        ("rng_mode", ctypes.c_int32), ("seed", ctypes.c_uint32),
+        ("strip_count", ctypes.c_uint16), ("strip_index", ctypes.c_uint16),
         ("seed_tex", ctypes.c_void_p),
     ]
 

@@ -773,12 +773,27 @@ int check_params(rt_ctx* c, const rt_params* p) {
                 p->width, p->height);
   if (p->sample_begin < 0 || p->sample_end < p->sample_begin) return fail(RT_ERR_INVALID, "bad sample range");
   if (p->rng_mode != RT_RNG_XORSHIFT_REF && p->rng_mode != RT_RNG_COUNTER) return fail(RT_ERR_INVALID, "bad rng_mode");
+  if (p->strip_count != 0 && p->strip_index >= p->strip_count)
+    return fail(RT_ERR_INVALID, "strip_index %u must be below strip_count %u", (unsigned)p->strip_index, (unsigned)p->strip_count);
   // the reference's generator is seeded per pixel and runs through the pixel's samples from the first one
   // (fs:105-110): a range that starts later would draw the first range's numbers again
   if (p->rng_mode == RT_RNG_XORSHIFT_REF && p->sample_begin != 0)
     return fail(RT_ERR_INVALID, "RT_RNG_XORSHIFT_REF renders samples from 0 only (sample_begin = %d): use RT_RNG_COUNTER for sample ranges",
                 p->sample_begin);
   return RT_OK;
+}
+
+// Rows of the call's share of its tile: the tile's rows, or with interleaving those of the share's strips of eight
+// (the tile's last strip may be short).
+int share_rows(const rt_params* p) {
+  const int th = p->tile_y1 - p->tile_y0;
+  if (p->strip_count == 0) return th;
+  const int strips = (th + 7) / 8, n = p->strip_count, r = p->strip_index;
+  if (r >= strips) return 0;
+  const int mine = (strips - r + n - 1) / n;
+  int rows = mine * 8;
+  if ((strips - 1) % n == r && th % 8 != 0) rows -= 8 - th % 8;  // the short last strip is mine
+  return rows;
 }
 
 template <typename K>
@@ -825,7 +840,7 @@ bool attach_overflow_fixed(rt_ctx* c, long long& blocks, scene_dev& sc, unsigned
 template <int SEARCH, int RNG, bool COUNTED>
 hipError_t launch_render_one(rt_ctx* c, const rt_params* p, hipStream_t st, render_args a) {
   using T = search_traits<SEARCH>;
-  const int tw = p->tile_x1 - p->tile_x0, th = p->tile_y1 - p->tile_y0;
+  const int tw = p->tile_x1 - p->tile_x0, th = a.vrows;
   const size_t lds = search_lds_bytes<SEARCH>(counts_of(c));
   hipError_t e = allow_lds(rt_render_kernel<SEARCH, RNG, COUNTED>, lds);
   if (e != hipSuccess) return e;
@@ -933,7 +948,8 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(rt_counters), c->stream));
     a.counters = c->counters.p;
   }
-  const int tw = p->tile_x1 - p->tile_x0, th = p->tile_y1 - p->tile_y0;
+  const int tw = p->tile_x1 - p->tile_x0, th = share_rows(p);
+  a.vrows = th;
   if (tw == 0 || th == 0 || p->sample_end == p->sample_begin) return RT_OK;
   auto launch = [&](const render_args& ra, const rt_params* rp) -> hipError_t {
     hipError_t qe = hipMemsetAsync(c->queue.p, 0, sizeof(unsigned long long), c->stream);
@@ -987,7 +1003,8 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
     e = launch(sw, p);
     if (e == hipSuccess) {
       rt_probe_sum_kernel<<<(unsigned)((n_rect + 255) / 256), 256, 0, c->stream>>>(
-          (uint32_t)n_rect, reinterpret_cast<const float4*>(c->probe_samples.p), n_samples, p->tile_x0, p->tile_y0, tw, p->width, c->accum(), nullptr, nullptr);
+          (uint32_t)n_rect, reinterpret_cast<const float4*>(c->probe_samples.p), n_samples, p->tile_x0, p->tile_y0, tw, p->width,
+          p->strip_count, p->strip_index, c->accum(), nullptr, nullptr);
       e = hipGetLastError();
     }
   } else if (!two_pass) {
@@ -1029,8 +1046,8 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
     e = launch(probe, p);
     if (e == hipSuccess && swept) {
       rt_probe_sum_kernel<<<(unsigned)((n_rect + 255) / 256), 256, 0, c->stream>>>(
-          (uint32_t)n_rect, reinterpret_cast<const float4*>(c->probe_samples.p), n_probe, p->tile_x0, p->tile_y0, tw, p->width, c->accum(), c->carry_colour.p,
-          c->carry_rng.p);
+          (uint32_t)n_rect, reinterpret_cast<const float4*>(c->probe_samples.p), n_probe, p->tile_x0, p->tile_y0, tw, p->width,
+          p->strip_count, p->strip_index, c->accum(), c->carry_colour.p, c->carry_rng.p);
       e = hipGetLastError();
       probe.pass = 1;  // what follows copies `probe` for the main pass
       probe.sweeps = 1;
@@ -1103,7 +1120,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
         const uint32_t cand = n < max_split ? n : max_split;
         rt_sum_split_kernel<<<(cand + 255) / 256, 256, 0, c->stream>>>(c->order_idx.p, c->plan_parts.p, cand, c->carry_colour.p,
                                                                       reinterpret_cast<const float4*>(c->split_samples.p), main_samples, cand, p->tile_x0, p->tile_y0,
-                                                                      tw, p->width, c->accum());
+                                                                      tw, p->width, p->strip_count, p->strip_index, c->accum());
         e = hipGetLastError();
       }
     }

@@ -75,8 +75,17 @@ inline size_t search_lds_bytes(const scene_counts& n) {
   return search_scene_lds_bytes<SEARCH>(n) + (size_t)T::waves * ((size_t)T::stack_words * 4 + T::stage_bytes);
 }
 
+// Rows of a call's share of its tile.  Without interleaving (strip_count 0) these are the tile's rows; with it, the
+// rows of the share's strips of eight one after the other ("virtual" rows): per-share arrays are indexed by virtual
+// row, and real_row gives the image row.
+RT_DEV int real_row(int vy, int tile_y0, int strip_count, int strip_index) {
+  if (strip_count == 0) return tile_y0 + vy;
+  return tile_y0 + (((vy >> 3) * strip_count + strip_index) << 3) + (vy & 7);
+}
+
 struct render_args {
   rt_params p;                 // seed_tex inside is a host pointer and is not used on the device
+  int vrows;                   // rows of this call's share of the tile (virtual rows, see real_row)
   scene_dev sc;
   float* accum;                // width*height*3 radiance sums
   const uint32_t* seed_tex;    // device copy of p.seed_tex, or null
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
   uint32_t stage;  // this wave's node staging area (byte offset into LDS)
   search_setup<SEARCH>(sc, sv, stack_col, stage);
 
-  const int tw = P.tile_x1 - P.tile_x0, th = P.tile_y1 - P.tile_y0;
+  const int tw = P.tile_x1 - P.tile_x0, th = A.vrows;
   const int tiles_x = (tw + 7) >> 3, tiles_y = (th + 7) >> 3;
   const uint32_t tile_items = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
   const uint32_t total_items = A.pass == 2 ? *A.n_jobs : (A.pass == 3 ? tile_items * (uint32_t)A.sweeps : tile_items);
@@ -465,11 +474,12 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
           exhausted = true;
         } else {
           uint4 job = make_uint4(0u, (uint32_t)P.sample_begin, (uint32_t)P.sample_end, RT_JOB_WHOLE);
+          int vy;
           if (A.pass == 2) {
             job = A.jobs[item];
             rect_pixel = job.x;
             x = P.tile_x0 + (int)(rect_pixel % (uint32_t)tw);
-            y = P.tile_y0 + (int)(rect_pixel / (uint32_t)tw);
+            vy = (int)(rect_pixel / (uint32_t)tw);
           } else {
             uint32_t it = item;
             if (A.pass == 3) {  // sweep q takes the q-th part of every pixel's probe samples
@@ -482,10 +492,11 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
             }
             const uint32_t tile = it >> 6, within = it & 63u;
             x = P.tile_x0 + (int)(tile % (uint32_t)tiles_x) * 8 + (int)(within & 7u);
-            y = P.tile_y0 + (int)(tile / (uint32_t)tiles_x) * 8 + (int)(within >> 3);
-            rect_pixel = (uint32_t)(y - P.tile_y0) * (uint32_t)tw + (uint32_t)(x - P.tile_x0);
+            vy = (int)(tile / (uint32_t)tiles_x) * 8 + (int)(within >> 3);
+            rect_pixel = (uint32_t)vy * (uint32_t)tw + (uint32_t)(x - P.tile_x0);
           }
-          if (x < P.tile_x1 && y < P.tile_y1) {
+          y = real_row(vy, P.tile_y0, P.strip_count, P.strip_index);
+          if (x < P.tile_x1 && vy < th) {
             have = true;
             pixel = (uint32_t)y * (uint32_t)P.width + (uint32_t)x;
             s = (int)job.y;
@@ -615,7 +626,8 @@ __global__ __launch_bounds__(256) void rt_plan_jobs_kernel(const uint32_t* order
 // probe pass carried, exactly as one lane would have added them.
 __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order, const uint32_t* parts, uint32_t n_candidates,
                                                           const float* carry_colour, const float4* split_samples, int samples,
-                                                          uint32_t n_rows, int tile_x0, int tile_y0, int tile_w, int width, float* accum) {
+                                                          uint32_t n_rows, int tile_x0, int tile_y0, int tile_w, int width,
+                                                          int strip_count, int strip_index, float* accum) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_candidates || parts[i] <= 1u) return;
   const uint32_t rect_pixel = order[i];
@@ -624,7 +636,7 @@ __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order
     const float4 v = split_samples[sample_slot((uint32_t)s, i, n_rows)];
     colour = colour + mk3(v.x, v.y, v.z);
   }
-  const int x = tile_x0 + (int)(rect_pixel % (uint32_t)tile_w), y = tile_y0 + (int)(rect_pixel / (uint32_t)tile_w);
+  const int x = tile_x0 + (int)(rect_pixel % (uint32_t)tile_w), y = real_row((int)(rect_pixel / (uint32_t)tile_w), tile_y0, strip_count, strip_index);
   float* dst = accum + 3 * ((size_t)y * (size_t)width + (size_t)x);
   dst[0] = colour.x;
   dst[1] = colour.y;
@@ -636,11 +648,11 @@ __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order
 // carry arrays (a probe: the main pass continues from it) or, with carry_colour null, back into the
 // image (a frame rendered in sweeps as a whole).
 __global__ __launch_bounds__(256) void rt_probe_sum_kernel(uint32_t n_rect, const float4* probe_samples, int n_probe, int tile_x0,
-                                                          int tile_y0, int tile_w, int width, float* accum,
-                                                          float* carry_colour, uint32_t* carry_rng) {
+                                                          int tile_y0, int tile_w, int width, int strip_count, int strip_index,
+                                                          float* accum, float* carry_colour, uint32_t* carry_rng) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_rect) return;
-  const int x = tile_x0 + (int)(i % (uint32_t)tile_w), y = tile_y0 + (int)(i / (uint32_t)tile_w);
+  const int x = tile_x0 + (int)(i % (uint32_t)tile_w), y = real_row((int)(i / (uint32_t)tile_w), tile_y0, strip_count, strip_index);
   float* base = accum + 3 * ((size_t)y * (size_t)width + (size_t)x);
   f3 colour = mk3(base[0], base[1], base[2]);
   for (int s = 0; s < n_probe; s++) {  // consecutive threads read consecutive lines of a group's plane

@@ -12,11 +12,14 @@ from dataclasses import dataclass
 
 @dataclass(frozen=True)
 class Share:
-    """What one rank renders: rows [y0,y1) of the image, samples [s0,s1) of each of their pixels."""
+    """What one rank renders: rows [y0,y1) of the image — all of them, or with strips > 0 the strips of eight rows
+    whose number is `strip` modulo `strips` — and samples [s0,s1) of each of their pixels."""
     y0: int
     y1: int
     s0: int
     s1: int
+    strips: int = 0
+    strip: int = 0
 
 
 def split_frame(height: int, samples: int, world: int, row_groups: int = 1):
@@ -37,11 +40,30 @@ def split_frame(height: int, samples: int, world: int, row_groups: int = 1):
     return shares
 
 
+def split_interleaved(height: int, samples: int, world: int, sample_groups: int = 1):
+    """Shares of `world` ranks for a frame whose rows differ in cost (sky above, spheres below): every rank takes
+    every (world / sample_groups)-th strip of eight rows over the whole height, and one of `sample_groups` sample
+    ranges.  Disjoint pixels per sample range, about equal cost per rank."""
+    if world < 1 or sample_groups < 1 or world % sample_groups:
+        raise ValueError("world must be a positive multiple of sample_groups")
+    strips = world // sample_groups
+    if samples < sample_groups:
+        raise ValueError("fewer samples than sample groups")
+    shares = []
+    for rank in range(world):
+        part, strip = divmod(rank, strips)
+        s0 = samples * part // sample_groups
+        s1 = samples * (part + 1) // sample_groups
+        shares.append(Share(0, height, s0, s1, strips if strips > 1 else 0, strip if strips > 1 else 0))
+    return shares
+
+
 def apply_share(params, share: Share):
-    """Copy of an rt_params restricted to a share (tile rows and sample range)."""
+    """Copy of an rt_params restricted to a share (tile rows, strips and sample range)."""
     p = params.copy()
     p.tile_y0, p.tile_y1 = share.y0, share.y1
     p.sample_begin, p.sample_end = share.s0, share.s1
+    p.strip_count, p.strip_index = share.strips, share.strip
     return p
 
 
