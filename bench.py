@@ -11,13 +11,17 @@ A step is one pass of the hot path over one batch of synthetic input:
   c5            the 487-sphere scene at 3840x2160, 4096 spp in total                -> Mpaths/s
 Scene and rays are resident in HBM before the timed region starts.
 
-With N > 1 (one process per GPU, started by torch.distributed.run) every rank
-renders its own 256-sample range of the same frame into its own accumulator
-(weak scaling: N x 256 spp in total) and the accumulators are summed onto rank
-0 with an RCCL reduce inside the timed step.  c4 splits the ray batch by index
-range and needs no collective.  c5 is the fixed-size job (strong scaling): the 4096 samples per pixel
-are divided among the ranks, by row band and sample range (two bands from four ranks on), and
-summed the same way.
+With N > 1 (one process per GPU, started by torch.distributed.run) the SAME
+job is divided among the ranks (strong scaling: `value` at N ranks over `value`
+at one rank is the speed-up): every rank renders every N-th strip of eight
+rows of the frame at the full sample count into its own accumulator, and the
+accumulators are summed onto rank 0 with an RCCL reduce inside the timed step,
+queued behind the render on the device.  c5 divides its 4096 samples per pixel
+by row band and sample range (two bands from four ranks on).  c4 splits the ray
+batch by index range and needs no collective.  `--scaling weak` gives every
+rank its own 256-sample range of the whole frame instead (N x the work); with
+N > 1 the line also carries that figure as `weak_scaling`, measured after the
+timed steps of the headline.
 
 Prints ONE JSON line on rank 0.
 """
@@ -72,7 +76,33 @@ def parse_args():
     ap.add_argument("--cpu-threads", type=int, default=16)
     # "gloo" rehearses the N > 1 flow on a box with fewer GPUs than ranks (ranks then share devices); never a result
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--bands", type=int, default=1, help="row bands per step whose sums overlap the next band's render (N > 1)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the linear-scan and weak-scaling legs")
     return ap.parse_args()
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def traffic_source():
+    """Where roofline.traffic comes from: the committed counter passes, with their date and commit."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            meta = json.load(f).get("_meta", {})
+    except (OSError, ValueError):
+        return None
+    return ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, (2*FETCH_SIZE + WRITE_SIZE)*1024 B "
+            f"per step, collected {meta.get('date', '?')} at commit {meta.get('commit', '?')}; not measured in this run")
 
 
 def cpu_baseline_render(rt, scene, cam, cfg, threads):
@@ -91,7 +121,8 @@ def cpu_baseline_render(rt, scene, cam, cfg, threads):
     t0 = time.perf_counter()
     _, c = oracle.render(scene, p, threads=threads)
     dt = time.perf_counter() - t0
-    out = {"value": c["paths"] / dt / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
+    out = {"value": c["paths"] / dt / 1e6, "unit": "Mpaths/s", "cores": threads, "host_cores": os.cpu_count(), "cpu_model": cpu_model(),
+           "kind": "port",
            "sample": f"same scene and camera, {w}x{h} at {spp} spp ({c['paths']} paths, {dt:.1f} s wall), "
                      f"CPU restatement of the reference shader (linear scan), {threads} threads"}
     # one thread, on a band of rows sized for about 5 s
@@ -117,7 +148,7 @@ def cpu_baseline_trace(rt, scene, threads, seed):
     t0 = time.perf_counter()
     oracle.trace(scene, o, d, threads=threads)
     dt = time.perf_counter() - t0
-    return {"value": n2 / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+    return {"value": n2 / dt / 1e6, "unit": "Mrays/s", "cores": threads, "host_cores": os.cpu_count(), "cpu_model": cpu_model(), "kind": "port",
             "sample": f"first {n2} rays of the batch against all {scene.n_spheres} spheres ({dt:.1f} s wall), "
                       f"CPU restatement of hit_any (linear scan), {threads} threads"}
 
@@ -186,14 +217,18 @@ def main():
 
         step(counted=True)
         counters = r.counters()
+        if counters["segments"]:
+            result["node_visits_per_ray"] = counters["trav_lane_steps"] / counters["segments"]
         units_per_step = n_rays_total
         unit, metric = "Mrays/s", "closest-hit rays per second (Mrays/s)"
         algo_bytes = 44.0 * n  # 24 B in + 20 B out per ray
+        info = r.scene_info()
         result["config"] = {"workload": cfg["workload"] if not (args.spheres or args.rays) else f"{n_sph} spheres, {n_rays_total}-ray closest-hit batch",
-                            "accel": args.accel, "spheres": n_sph, "rays": n_rays_total, "lbvh_depth": r.lbvh_depth(),
+                            "accel": args.accel, "builder": info["builder"], "tree_nodes": info["n_nodes"], "node_bytes": info["node_bytes"],
+                            "spheres": n_sph, "rays": n_rays_total, "lbvh_depth": r.lbvh_depth(), "ranks": world,
                             "parallelism": f"ray index ranges x{world}"}
         if accel == rt.ACCEL_LBVH:
-            result["lbvh_build_ms"] = r.last_build_ms()
+            result["build_ms"] = r.last_build_ms()
     else:
         scene = rt.build_scene(sid)
         cam = rt.scene_camera(sid)
@@ -205,33 +240,48 @@ def main():
         accum = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
         r.set_accumulator(accum.data_ptr(), w, h)
         from raytrace_amd import distributed as rtd
-        strong = bool(cfg.get("strong"))
-        total_spp = spp if strong else spp * world
-        # weak: rank r renders samples [r*spp, (r+1)*spp) of every pixel; strong: a row band x sample range of the fixed job
-        share = rtd.split_frame(h, total_spp, world, row_groups=2 if strong and world >= 4 and world % 2 == 0 else 1)[rank]
-        p = rtd.apply_share(rt.make_params(cam, w, h, total_spp, rng_mode=rng_mode), share)
+        strong = args.scaling == "strong" or bool(cfg.get("strong"))
 
-        def step(counted=False):
-            r.clear()  # memset + render are ordered on the library's own stream
-            r.render(p, counted=counted)
-            if world > 1:
-                r.synchronize()
-                rtd.combine(accum, dst=0)  # RCCL sum of the per-GPU accumulators onto rank 0
-                torch.cuda.current_stream().synchronize()  # before the next step clears the buffer
+        def share_params(strongly):
+            total = spp if strongly else spp * world
+            if not strongly:      # weak: rank r renders samples [r*spp, (r+1)*spp) of every pixel
+                share = rtd.split_frame(h, total, world)[rank]
+            elif cfg.get("strong"):  # c5: row bands x sample ranges of the fixed job
+                share = rtd.split_frame(h, total, world, row_groups=2 if world >= 4 and world % 2 == 0 else 1)[rank]
+            else:                 # every world-th strip of eight rows, all samples: disjoint pixels, balanced cost
+                share = rtd.split_interleaved(h, total, world)[rank]
+            return rtd.apply_share(rt.make_params(cam, w, h, total, rng_mode=rng_mode), share), total
 
+        p, total_spp = share_params(strong)
+
+        def make_step(params):
+            def step(counted=False):
+                r.clear()  # memset + render are ordered on the library's own stream
+                if world > 1 and not counted:
+                    # render and RCCL sum onto rank 0, the sum queued behind the render on the device
+                    rtd.render_and_combine(r, params, accum, dst=0, bands=args.bands)
+                else:
+                    r.render(params, counted=counted)
+            return step
+
+        step = make_step(p)
         step(counted=True)
         counters = r.counters()
         units_per_step = w * h * total_spp
         unit, metric = "Mpaths/s", "path-tracing throughput at %dx%d (Mpaths/s)" % (w, h)
         algo_bytes = None
+        info = r.scene_info()
         result["config"] = {"workload": f"{cfg['workload'].split(' ')[0]} scene {w}x{h}x{spp}spp depth50" if (args.width or args.height or args.spp) else cfg["workload"],
-                            "accel": args.accel, "spheres": scene.n_spheres, "rng": cfg["rng"],
+                            "accel": args.accel, "builder": info["builder"], "tree_nodes": info["n_nodes"], "tree_in_lds": bool(info["tree_in_lds"]),
+                            "spheres": scene.n_spheres, "rng": cfg["rng"],
                             "lbvh_depth": r.lbvh_depth(), "global_samples_per_pixel": total_spp,
-                            "parallelism": (f"row bands x sample ranges over {world} ranks + RCCL reduce" if strong else
-                                            f"sample ranges x{world} + RCCL reduce") if world > 1 else "single GPU"}
+                            "ranks": world, "collective": (f"{args.backend} reduce to rank 0, {args.bands} band(s) per step" if world > 1 else None),
+                            "parallelism": ("single GPU" if world == 1 else
+                                            f"row bands x sample ranges over {world} ranks" if cfg.get("strong") else
+                                            f"{world} interleaved sets of 8-row strips" if strong else f"sample ranges x{world}")}
         result["_scaling"] = "strong" if strong else "weak"
         if accel == rt.ACCEL_LBVH:
-            result["lbvh_build_ms"] = r.last_build_ms()
+            result["build_ms"] = r.last_build_ms()
 
     for _ in range(args.warmup):
         step()
@@ -254,6 +304,43 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    def timed(stepfn, n):
+        """Max over ranks of the wall time of n steps between two barriers."""
+        stepfn()
+        barrier()
+        t_ = time.perf_counter()
+        for _ in range(n):
+            stepfn()
+        barrier()
+        dt_ = time.perf_counter() - t_
+        if world > 1:
+            tm = torch.tensor([dt_], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dt_ = float(tm.item())
+        return dt_
+
+    extras = {}
+    if args.config != "c4" and not args.no_extras:
+        if world > 1 and not cfg.get("strong"):   # the other scaling mode, after the headline's timed steps
+            other, other_total = share_params(not strong)
+            dt_ = timed(make_step(other), args.steps)
+            extras["weak_scaling" if strong else "strong_scaling"] = {
+                "value": w * h * other_total * args.steps / dt_ / 1e6, "unit": "Mpaths/s", "ms_per_step": dt_ / args.steps * 1e3,
+                "global_samples_per_pixel": other_total}
+        if world == 1 and args.accel == "lbvh" and args.config in ("c2", "c1"):   # the reference's algorithm on the same frame
+            r.upload(scene, rt.ACCEL_LINEAR)
+            n_lin = max(1, min(args.steps, 2))
+            dt_ = timed(step, n_lin)
+            ms_lin, k_lin = r.last_kernel_ms()
+            r.clear()
+            r.render(p, counted=True)
+            c_lin = r.counters()
+            lin_flops = rt.algorithmic_flops(c_lin)
+            extras["linear_scan"] = {"value": units_per_step * n_lin / dt_ / 1e6, "unit": unit, "kernel": k_lin, "kernel_ms": ms_lin,
+                                     "roofline_frac": lin_flops / (ms_lin * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                                     "algorithmic_gflop_per_launch": lin_flops / 1e9}
+            r.upload(scene, accel)
 
     if rank == 0:
         flops = rt.algorithmic_flops(counters)
@@ -279,6 +366,8 @@ def main():
                                   "algorithmic_gflop_per_launch": flops / 1e9}
         if traffic:  # fabric bytes (Infinity Cache + HBM reads behind L2, and writes) per second of kernel time
             result["roofline"]["traffic_gbs"] = traffic / (avg_kernel_ms * 1e-3) / 1e9
+            result["roofline"]["traffic_source"] = traffic_source()
+        result.update(extras)
         result["counters_per_launch"] = counters
         if not args.no_cpu_baseline and world == 1:
             threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))

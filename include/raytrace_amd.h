@@ -324,6 +324,32 @@ RT_API int rt_last_kernel_ms(rt_ctx* ctx, float* ms, const char** kernel_name);
 /* Device time of the last LBVH build (all of its kernels), in milliseconds. */
 RT_API int rt_last_build_ms(rt_ctx* ctx, float* ms);
 
+/* What rt_scene_upload made of the scene (no counterpart in the reference, which has only its scan). */
+enum { RT_BUILDER_NONE = 0, RT_BUILDER_HOST_SAH = 1, RT_BUILDER_DEVICE_LBVH = 2 };
+typedef struct rt_scene_info {
+  int32_t n_spheres, n_materials;
+  int32_t accel;        /* RT_ACCEL_* asked for                                                     */
+  int32_t builder;      /* RT_BUILDER_*: surface-area tree built on the host (scenes that fit LDS),
+                           Morton-order LBVH built on the device, or none (linear scan)             */
+  int32_t n_big;        /* spheres kept out of the tree and tested exactly for every ray            */
+  int32_t n_leaf;       /* spheres in the tree                                                      */
+  int32_t n_nodes;      /* 4-wide nodes                                                             */
+  int32_t depth;        /* binary levels (rt_lbvh_depth)                                            */
+  int32_t tree_in_lds;  /* 1: the kernels keep tree, hit-record and material arrays in LDS          */
+  int32_t pad_per_ray;  /* 1: one box pad per ray, 0: per child box                                 */
+  int32_t node_bytes;   /* bytes of one node as the kernels read it                                 */
+  int32_t reserved[5];
+} rt_scene_info;
+RT_API int rt_get_scene_info(rt_ctx* ctx, rt_scene_info* out);
+
+/*
+ * The HIP stream (a hipStream_t) every asynchronous call of the context is
+ * queued on, for callers that order their own device work against it without
+ * a host wait: record an event on it and make another stream wait, e.g. before
+ * a collective sums the accumulator (no counterpart in the reference).
+ */
+RT_API int rt_get_stream(rt_ctx* ctx, void** hip_stream);
+
 /* Depth of the LBVH of the uploaded scene (largest number of ancestors of a
  * leaf; it sizes the traversal stack).  0 for the linear scan. */
 RT_API int rt_lbvh_depth(rt_ctx* ctx);

@@ -243,6 +243,17 @@ class Renderer:
         self._check(self.lib.rt_last_build_ms(self.ctx, ctypes.byref(ms)))
         return float(ms.value)
 
+    def scene_info(self):
+        info = _lib.RtSceneInfo()
+        self._check(self.lib.rt_get_scene_info(self.ctx, ctypes.byref(info)))
+        return info.as_dict()
+
+    def stream(self):
+        """The context's hipStream_t as an integer (wrap it with torch.cuda.ExternalStream to order torch work after it)."""
+        st = ctypes.c_void_p()
+        self._check(self.lib.rt_get_stream(self.ctx, ctypes.byref(st)))
+        return st.value or 0
+
     def lbvh_depth(self):
         return int(self.lib.rt_lbvh_depth(self.ctx))
 

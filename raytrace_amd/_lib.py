@@ -53,6 +53,17 @@ class RtCounters(ctypes.Structure):
         return {name: int(getattr(self, name)) for name in COUNTER_FIELDS}
 
 
+class RtSceneInfo(ctypes.Structure):
+    """struct rt_scene_info of include/raytrace_amd.h."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("n_spheres", "n_materials", "accel", "builder", "n_big", "n_leaf", "n_nodes",
+                                               "depth", "tree_in_lds", "pad_per_ray", "node_bytes")] + [("reserved", ctypes.c_int32 * 5)]
+
+    def as_dict(self):
+        d = {n: int(getattr(self, n)) for n, _ in self._fields_[:-1]}
+        d["builder"] = {0: "none", 1: "host_sah", 2: "device_lbvh"}[d["builder"]]
+        return d
+
+
 class RtCamera(ctypes.Structure):
     """struct rt_camera of include/raytrace_amd_host.h."""
     _fields_ = [
@@ -69,7 +80,7 @@ DEVICE_SYMBOLS = [
     "rt_clear", "rt_set_accumulator", "rt_set_accumulated_samples", "rt_readback", "rt_trace_batch",
     "rt_trace_batch_device", "rt_synchronize", "rt_get_counters", "rt_last_kernel_ms", "rt_last_build_ms",
     "rt_lbvh_depth", "rt_device_count", "rt_seed_texture", "rt_accumulator_read", "rt_accumulator_write",
-    "rt_render_chunk", "rt_trace_batch_noalloc", "rt_eval_perlin", "rt_eval_perlin_gradient", "rt_set_scratch_budget",
+    "rt_render_chunk", "rt_trace_batch_noalloc", "rt_eval_perlin", "rt_eval_perlin_gradient", "rt_set_scratch_budget", "rt_get_scene_info", "rt_get_stream",
 ]
 HOST_SYMBOLS = ["rt_host_camera", "rt_host_build_scene", "rt_host_scene_camera", "rt_host_gen_rays",
                 "rt_host_blit_nearest", "rt_host_height_for_width", "rt_host_write_ppm",
@@ -167,6 +178,10 @@ def device_lib():
                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.rt_set_scratch_budget.restype = ctypes.c_int
         lib.rt_set_scratch_budget.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]
+        lib.rt_get_scene_info.restype = ctypes.c_int
+        lib.rt_get_scene_info.argtypes = [ctypes.c_void_p, P(RtSceneInfo)]
+        lib.rt_get_stream.restype = ctypes.c_int
+        lib.rt_get_stream.argtypes = [ctypes.c_void_p, P(ctypes.c_void_p)]
         lib.rt_eval_perlin.restype = ctypes.c_int
         lib.rt_eval_perlin.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
         lib.rt_eval_perlin_gradient.restype = ctypes.c_int

@@ -147,7 +147,7 @@ struct rt_ctx {
   bool have_noise = false;
   // hierarchy
   int search = SEARCH_LINEAR;
-  int n_big = 0, n_leaf = 0, n_nodes = 0, root = 0, depth = 0;
+  int n_big = 0, n_leaf = 0, n_nodes = 0, root = 0, depth = 0, builder = RT_BUILDER_NONE;
   dev_buf<float4> big_sph;
   dev_buf<int32_t> big_idx;
   dev_buf<float4> tree_sph;   // spheres of the tree, upload order among themselves
@@ -1315,6 +1315,7 @@ int rt_scene_upload(rt_ctx* c, const void* spheres_std140, int n_spheres, const 
   c->n_nodes = 0;
   c->depth = 0;
   c->have_build_time = false;
+  c->builder = RT_BUILDER_NONE;
   if (accel == RT_ACCEL_LBVH && c->n_leaf > 0) {
     bool built = false;
     if (host_builder_enabled() && c->n_leaf >= 2 && c->n_leaf <= kSahMaxLeaves) {
@@ -1331,9 +1332,11 @@ int rt_scene_upload(rt_ctx* c, const void* spheres_std140, int n_spheres, const 
         built = (search == SEARCH_TREE_LDS_RAY || search == SEARCH_TREE_LDS_NODE) && c->depth <= 2 * kSahMaxWideDepth;
       }
     }
+    c->builder = RT_BUILDER_HOST_SAH;
     if (!built) {
       rc = build_lbvh(c);
       if (rc) return rc;
+      c->builder = RT_BUILDER_DEVICE_LBVH;
     }
   }
   c->search = choose_search(c);
@@ -1707,6 +1710,30 @@ int rt_last_build_ms(rt_ctx* c, float* ms) {
 }
 
 int rt_lbvh_depth(rt_ctx* c) { return c ? c->depth : 0; }
+
+int rt_get_scene_info(rt_ctx* c, rt_scene_info* out) {
+  if (!c || !out) return fail(RT_ERR_INVALID, "null argument");
+  if (!c->have_scene) return fail(RT_ERR_STATE, "no scene uploaded");
+  std::memset(out, 0, sizeof(*out));
+  out->n_spheres = c->n_spheres;
+  out->n_materials = c->n_materials;
+  out->accel = c->accel;
+  out->builder = c->builder;
+  out->n_big = c->n_big;
+  out->n_leaf = c->n_leaf;
+  out->n_nodes = c->n_nodes;
+  out->depth = c->depth;
+  out->tree_in_lds = c->search == SEARCH_TREE_LDS_RAY || c->search == SEARCH_TREE_LDS_NODE;
+  out->pad_per_ray = c->search == SEARCH_TREE_LDS_RAY || c->search == SEARCH_TREE_GLB_RAY;
+  out->node_bytes = c->n_nodes > 0 ? (int)sizeof(bvh4_node) : 0;
+  return RT_OK;
+}
+
+int rt_get_stream(rt_ctx* c, void** hip_stream) {
+  if (!c || !hip_stream) return fail(RT_ERR_INVALID, "null argument");
+  *hip_stream = reinterpret_cast<void*>(c->stream);
+  return RT_OK;
+}
 
 int rt_seed_texture(rt_ctx* c, int width, int height, float grid_size, float contrast, int layers, float lacunarity,
                     uint32_t* seed_tex) {

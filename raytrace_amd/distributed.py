@@ -67,8 +67,52 @@ def apply_share(params, share: Share):
     return p
 
 
-def combine(accum, dst: int = 0, group=None):
-    """Sum the ranks' accumulators (a torch tensor, device or CPU) onto rank `dst`."""
+def combine(accum, dst: int = 0, group=None, after=None, async_op=False):
+    """Sum the ranks' accumulators (a torch tensor, device or CPU) onto rank `dst`.
+
+    after: a Renderer whose queued work writes `accum`.  The sum is ordered behind it on the device — an event on the
+    renderer's stream that torch's current stream waits for — with no host wait in between."""
     import torch.distributed as dist
-    dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
-    return accum
+    device_ordered = accum.is_cuda and dist.get_backend(group) == "nccl"
+    if after is not None and accum.is_cuda:
+        if device_ordered:
+            import torch
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.ExternalStream(after.stream()))
+            torch.cuda.current_stream().wait_event(ev)
+        else:
+            after.synchronize()  # gloo stages device tensors through the host on streams of its own: wait here
+    work = dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=async_op and device_ordered)
+    return work if device_ordered else None
+
+
+def band_rows(height: int, bands: int, strips: int):
+    """Cut [0, height) into at most `bands` runs of rows whose starts are multiples of 8 * max(strips, 1), so that a
+    share's strips of eight keep their numbers inside every band."""
+    unit = 8 * max(strips, 1)
+    units = (height + unit - 1) // unit
+    bands = max(1, min(bands, units))
+    cuts = [min(height, unit * (units * b // bands)) for b in range(bands + 1)]
+    return [(cuts[b], cuts[b + 1]) for b in range(bands) if cuts[b + 1] > cuts[b]]
+
+
+def render_and_combine(renderer, params, accum, dst: int = 0, bands: int = 4, group=None):
+    """One frame share, rendered band by band into `accum` (float32 [H, W, 3] on the renderer's device, already set as
+    its accumulator) and summed onto rank `dst` band by band: the collective of band k is queued behind the render
+    of band k on the device and runs beside the render of band k + 1.  Returns when everything is queued; the
+    caller's stream (torch's current one) is ordered behind the last sum, and the renderer's stream behind it too,
+    so that the next frame's clear cannot overtake the sums."""
+    import torch
+    works = []
+    for y0, y1 in band_rows(params.tile_y1 - params.tile_y0, bands, params.strip_count):
+        p = params.copy()
+        p.tile_y0, p.tile_y1 = params.tile_y0 + y0, params.tile_y0 + y1
+        renderer.render(p)
+        works.append(combine(accum[p.tile_y0:p.tile_y1], dst=dst, group=group, after=renderer, async_op=True))
+    for w in works:
+        if w is not None:
+            w.wait()  # orders torch's current stream behind the collective (no host wait for device tensors)
+    if accum.is_cuda:
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream())
+        torch.cuda.ExternalStream(renderer.stream()).wait_event(done)
