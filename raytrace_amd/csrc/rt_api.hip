@@ -154,6 +154,7 @@ struct rt_ctx {
   dev_buf<float> tree_r;
   dev_buf<int32_t> tree_orig; // -> upload index
   dev_buf<bvh4_node> nodes;
+  dev_buf<bvh4q_node> qnodes;  // the 64-byte form of the nodes, for trees the kernels read from HBM
   dev_buf<float4> leaf_sph;
   dev_buf<float> leaf_r;
   dev_buf<int32_t> leaf_idx;
@@ -209,6 +210,7 @@ struct rt_ctx {
     s.n_leaf = n_leaf;
     s.n_nodes = n_nodes;
     s.nodes = nodes.p;
+    s.qnodes = qnodes.p;
     s.leaf_sph = leaf_sph.p;
     s.leaf_idx = leaf_idx.p;
     s.root = root;
@@ -1183,7 +1185,7 @@ void rt_destroy(rt_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->sph.release(); c->inv_r.release(); c->sph_mat.release(); c->mat_type.release(); c->mat_a.release();
   c->big_sph.release(); c->big_idx.release(); c->tree_sph.release(); c->tree_r.release(); c->tree_orig.release();
-  c->nodes.release(); c->leaf_sph.release(); c->leaf_r.release(); c->leaf_idx.release();
+  c->nodes.release(); c->qnodes.release(); c->leaf_sph.release(); c->leaf_r.release(); c->leaf_idx.release();
   c->accum_own.release(); c->seed_tex.release(); c->queue.release(); c->counters.release(); c->ovf.release(); c->build.release(); c->perlin_grad.release();
   c->carry_colour.release(); c->carry_rng.release(); c->carry_cost.release(); c->carry_key.release(); c->carry_idx.release();
   c->plan_parts.release(); c->plan_first.release(); c->plan_counts.release(); c->plan_total.release();
@@ -1340,6 +1342,12 @@ int rt_scene_upload(rt_ctx* c, const void* spheres_std140, int n_spheres, const 
     }
   }
   c->search = choose_search(c);
+  if ((c->search == SEARCH_TREE_GLB_RAY || c->search == SEARCH_TREE_GLB_NODE) && c->n_nodes > 0) {
+    HIP_TRY(c->qnodes.resize((size_t)c->n_nodes));
+    lbvh_quantize_kernel<<<(unsigned)((c->n_nodes + 255) / 256), 256, 0, c->stream>>>(c->nodes.p, c->n_nodes, c->qnodes.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   c->have_scene = true;
   return RT_OK;
 }
@@ -1725,7 +1733,7 @@ int rt_get_scene_info(rt_ctx* c, rt_scene_info* out) {
   out->depth = c->depth;
   out->tree_in_lds = c->search == SEARCH_TREE_LDS_RAY || c->search == SEARCH_TREE_LDS_NODE;
   out->pad_per_ray = c->search == SEARCH_TREE_LDS_RAY || c->search == SEARCH_TREE_GLB_RAY;
-  out->node_bytes = c->n_nodes > 0 ? (int)sizeof(bvh4_node) : 0;
+  out->node_bytes = c->n_nodes > 0 ? (out->tree_in_lds ? (int)sizeof(bvh4_node) : (int)sizeof(bvh4q_node)) : 0;
   return RT_OK;
 }
 

@@ -156,6 +156,7 @@ template <int SEARCH>
 RT_DEV void search_setup(const scene_dev& sc, scene_view& sv, uint32_t*& stack_col, uint32_t& stage) {
   using T = search_traits<SEARCH>;
   sv.nodes = sc.nodes;
+  sv.qnodes = sc.qnodes;
   sv.leaf_sph = sc.leaf_sph;
   sv.leaf_idx = sc.leaf_idx;
   sv.scan_sph = sc.sph;
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
         RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
         RT_COUNT(k, trav_lane_steps, node_lane ? 1u : 0u);
         uint32_t staged = 0u;  // the whole wave fetches the nodes its lanes want
-        if (search_traits<SEARCH>::staged) staged = stage_nodes(sv.nodes, node_lane ? srch.node_wanted() : -1, stage);
+        if (search_traits<SEARCH>::staged) staged = stage_nodes(sv.qnodes, node_lane ? srch.node_wanted() : -1, stage);
         if (node_lane) srch.step_node(sv, stack_col, staged, k);
       }
       RT_CLK_STOP(0);
@@ -731,7 +732,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
         RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
         RT_COUNT(k, trav_lane_steps, node_lane ? 1u : 0u);
         uint32_t staged = 0u;  // the whole wave fetches the nodes its lanes want
-        if (search_traits<SEARCH>::staged) staged = stage_nodes(sv.nodes, node_lane ? srch.node_wanted() : -1, stage);
+        if (search_traits<SEARCH>::staged) staged = stage_nodes(sv.qnodes, node_lane ? srch.node_wanted() : -1, stage);
         if (node_lane) srch.step_node(sv, stack_col, staged, k);
       }
     }

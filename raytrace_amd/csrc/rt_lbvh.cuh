@@ -264,3 +264,85 @@ __global__ __launch_bounds__(256) void lbvh_collapse_kernel(const float4* leaf_s
   }
   nodes[slot] = nd;
 }
+
+// ---- 64-byte nodes for trees read from HBM ------------------------------------
+// One thread per 4-wide node: the children's boxes onto a byte grid over their union (bvh4q_node).  Low planes are
+// rounded down and high planes up, checked in double against the decoded value, so that the decoded box holds the
+// child's box.
+#include <hip/hip_fp16.h>
+__global__ __launch_bounds__(256) void lbvh_quantize_kernel(const bvh4_node* nodes, int n_nodes, bvh4q_node* out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_nodes) return;
+  const bvh4_node nd = nodes[i];
+  bvh4q_node q;
+  q.exps = 0u;
+  unsigned short rh[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    q.ref[s] = nd.ref[s];
+    const float r = nd.ref[s] == RT_REF_EMPTY ? 0.0f : fminf(fmaxf(nd.rmin[s], 0.0f), 65504.0f);  // (a NaN radius: 0)
+    rh[s] = __half_as_ushort(__float2half_rz(r));
+  }
+  q.rmin_h[0] = (uint32_t)rh[0] | ((uint32_t)rh[1] << 16);
+  q.rmin_h[1] = (uint32_t)rh[2] | ((uint32_t)rh[3] << 16);
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float* lo = a == 0 ? nd.lox : a == 1 ? nd.loy : nd.loz;
+    const float* hi = a == 0 ? nd.hix : a == 1 ? nd.hiy : nd.hiz;
+    float ulo = __builtin_inff(), uhi = -__builtin_inff();
+    bool any_nan = false;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      if (nd.ref[s] == RT_REF_EMPTY) continue;
+      any_nan = any_nan || lo[s] != lo[s] || hi[s] != hi[s];
+      ulo = fminf(ulo, lo[s]);
+      uhi = fmaxf(uhi, hi[s]);
+    }
+    const double ext = (double)uhi - (double)ulo;
+    int e = 0;
+    bool grid = !any_nan && ulo > -3.0e38f && uhi < 3.0e38f && ext >= 0.0;
+    if (grid) {
+      if (ext > 0.0) {
+        (void)frexp(ext / 254.0, &e);  // ext / 254 = m * 2^e with m in [0.5, 1): a step of 2^e covers the extent in 254 steps
+      } else {
+        e = -126;
+      }
+      e = e < -126 ? -126 : e;
+      grid = e <= 127;
+    }
+    uint32_t wlo = 0u, whi = 0u;
+    float org;
+    if (grid) {
+      org = ulo;
+      const double step = ldexp(1.0, e);
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        int ql = 255, qh = 0;  // unused slot: inverted
+        if (nd.ref[s] != RT_REF_EMPTY) {
+          ql = (int)floor(((double)lo[s] - (double)org) / step);
+          ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
+          while (ql > 0 && (double)org + ql * step > (double)lo[s]) ql--;
+          qh = (int)ceil(((double)hi[s] - (double)org) / step);
+          qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+          while (qh < 255 && (double)org + qh * step < (double)hi[s]) qh++;
+        }
+        wlo |= (uint32_t)ql << (8 * s);
+        whi |= (uint32_t)qh << (8 * s);
+      }
+    } else {  // an extent that is not finite: every child passes on this axis
+      org = -3.402823466e38f;
+      e = 127;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const bool used = nd.ref[s] != RT_REF_EMPTY;
+        wlo |= (uint32_t)(used ? 0 : 255) << (8 * s);
+        whi |= (uint32_t)(used ? 255 : 0) << (8 * s);
+      }
+    }
+    q.org[a] = org;
+    q.exps |= (uint32_t)(e + 127) << (8 * a);
+    q.qlo[a] = wlo;
+    q.qhi[a] = whi;
+  }
+  out[i] = q;
+}

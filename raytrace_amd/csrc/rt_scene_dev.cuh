@@ -18,6 +18,26 @@ struct __attribute__((aligned(16))) bvh4_node {
   float rmin[4];
 };
 
+// The same node as trees read from HBM carry it: 64 bytes, what one group of four lanes fetches with one 64-byte
+// access.  The children's planes are bytes on a grid laid over the box of all four: plane = org + q * 2^(e - 127)
+// per axis, low planes rounded down and high planes up at build time, so that a decoded box holds the child's box
+// (whose growing rule then applies unchanged: the decoded box holds every sphere below).  rmin travels as binary16
+// rounded toward zero (a smaller rmin only grows the pad).  An axis whose extent is not finite takes org = -FLT_MAX
+// and the largest step: its planes decode to -FLT_MAX and +infinity, every child passes on that axis.
+//   piece 0: org.x org.y org.z | exps (byte a: biased exponent of the step on axis a)
+//   piece 1: qlo.x[4] | qlo.y[4] | qlo.z[4] | qhi.x[4]      (byte ch of a word: child ch)
+//   piece 2: qhi.y[4] | qhi.z[4] | rmin[0..1] | rmin[2..3]  (binary16 pairs)
+//   piece 3: ref[4]
+struct __attribute__((aligned(16))) bvh4q_node {
+  float org[3];
+  uint32_t exps;
+  uint32_t qlo[3];
+  uint32_t qhi[3];
+  uint32_t rmin_h[2];
+  int32_t ref[4];
+};
+static_assert(sizeof(bvh4q_node) == 64, "one 64-byte access per node");
+
 struct scene_dev {
   int32_t n_spheres;    // all spheres, upload order
   int32_t n_materials;
@@ -35,7 +55,8 @@ struct scene_dev {
   const int32_t* big_idx;   // upload index, ascending
   int32_t n_leaf;           // spheres in the tree
   int32_t n_nodes;          // 4-wide nodes
-  const bvh4_node* nodes;
+  const bvh4_node* nodes;   // trees the kernels hold in LDS
+  const bvh4q_node* qnodes; // trees read from HBM
   const float4* leaf_sph;   // Morton order
   const int32_t* leaf_idx;  // Morton position -> upload index
   int32_t root;             // reference of the root (a leaf reference when n_leaf == 1)
@@ -54,6 +75,7 @@ struct scene_dev {
 // The arrays a kernel actually reads: the HBM originals or their LDS copies.
 struct scene_view {
   const bvh4_node* nodes;
+  const bvh4q_node* qnodes;
   const float4* leaf_sph;
   const int32_t* leaf_idx;
   const float4* scan_sph;   // upload-order spheres for the linear scan
@@ -345,6 +367,20 @@ RT_DEV void child_interval(float lx, float ly, float lz, float hx, float hy, flo
   tf = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), limit);
 }
 
+// The same for a box given relative to the ray origin (a = lo - o, b = hi - o per axis), PAD_NODE rule.
+RT_DEV void child_interval_rel(float ax, float ay, float az, float bx, float by, float bz, float rmin, const slab_consts& s, float limit,
+                               float& tn, float& tf) {
+  const float pad = box_pad(fmaxf(-ax, bx), fmaxf(-ay, by), fmaxf(-az, bz), rmin);
+  const float t0x = (ax - pad) * s.inv_d.x, t1x = (bx + pad) * s.inv_d.x;
+  const float t0y = (ay - pad) * s.inv_d.y, t1y = (by + pad) * s.inv_d.y;
+  const float t0z = (az - pad) * s.inv_d.z, t1z = (bz + pad) * s.inv_d.z;
+  tn = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), RT_T_FLOOR);
+  tf = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), limit);
+}
+
+RT_DEV float byte_of(uint32_t w, int ch) { return (float)((w >> (8 * ch)) & 255u); }
+RT_DEV float half_of(uint32_t w, int hi) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(hi ? w >> 16 : w & 0xFFFFu)); }
+
 // Node fetch for trees read from HBM.  A lane that loads its own 128-byte node with eight 16-byte
 // loads costs the CU's vector cache eight tag look-ups per lane, 512 per wave and step, and that
 // look-up rate (about one per clock) is what bounds an incoherent closest-hit batch.  So the first
@@ -368,7 +404,7 @@ RT_DEV void child_interval(float lx, float ly, float lz, float hx, float hy, flo
 #define RT_STAGE_ROW 1040   // 64 lanes x 16 bytes + 16: the rows start in different banks
 #define RT_STAGE_BYTES (RT_STAGE_PIECES * RT_STAGE_ROW + 256)
 extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds[];
-RT_DEV uint32_t stage_nodes(const bvh4_node* nodes, int my_node, uint32_t stage_offset) {
+RT_DEV uint32_t stage_nodes(const bvh4q_node* nodes, int my_node, uint32_t stage_offset) {
   constexpr int G = RT_STAGE_PIECES;  // lanes of a group = passes = staged pieces
   static_assert(G == 4 || G == 8, "a group reads 64 or 128 consecutive bytes");
   unsigned char* stage = rt_lds + stage_offset;
@@ -392,14 +428,14 @@ RT_DEV uint32_t stage_nodes(const bvh4_node* nodes, int my_node, uint32_t stage_
 #pragma unroll
   for (int p = 0; p < G; p++) {
     if (w[p] >= 0)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)w[p] * sizeof(bvh4_node)),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)w[p] * sizeof(bvh4q_node)),
                                        (__attribute__((address_space(3))) void*)(stage + p * RT_STAGE_ROW), 16, 0, 0);
   }
 #else
   // through registers: all loads first (a pass nobody wants reads node 0), then the stores
   float4 piece[G];
 #pragma unroll
-  for (int p = 0; p < G; p++) piece[p] = *reinterpret_cast<const float4*>(base + (size_t)max(w[p], 0) * sizeof(bvh4_node));
+  for (int p = 0; p < G; p++) piece[p] = *reinterpret_cast<const float4*>(base + (size_t)max(w[p], 0) * sizeof(bvh4q_node));
 #pragma unroll
   for (int p = 0; p < G; p++) *reinterpret_cast<float4*>(stage + p * RT_STAGE_ROW + lane * 16) = piece[p];
 #endif
@@ -553,11 +589,40 @@ struct tree_search {
   RT_DEV void step_node(const scene_view& sv, trav_stack<PACKED> stk, uint32_t staged, lane_counters& k) {
     const unsigned char* nd = rt_lds + staged;
     if (PACKED) nd = reinterpret_cast<const unsigned char*>(sv.nodes) + __umul24((unsigned)cur, (unsigned)RT_LDS_NODE_STRIDE);  // (full-rate multiply)
-    const int4 ref = PACKED ? reinterpret_cast<const int4*>(nd)[6]
-                            : *reinterpret_cast<const int4*>(reinterpret_cast<const unsigned char*>(sv.nodes) + (size_t)cur * sizeof(bvh4_node) + 96);
-    const int refs[4] = {ref.x, ref.y, ref.z, ref.w};
+    int4 ref;
     float tn[4], tf[4];
-    if (SELECT) {
+    if (!PACKED) {
+      // trees read from HBM: the whole 64-byte node lies in the wave's staging area (stage_nodes)
+      stage_wait();
+      const uint4 p0 = *reinterpret_cast<const uint4*>(nd), p1 = *reinterpret_cast<const uint4*>(nd + 16),
+                  p2 = *reinterpret_cast<const uint4*>(nd + 32);
+      ref = *reinterpret_cast<const int4*>(nd + 48);
+      const float sx = __uint_as_float((p0.w & 255u) << 23), sy = __uint_as_float(((p0.w >> 8) & 255u) << 23),
+                  sz = __uint_as_float(((p0.w >> 16) & 255u) << 23);
+      const float gx = __uint_as_float(p0.x), gy = __uint_as_float(p0.y), gz = __uint_as_float(p0.z);
+      if (PAD_RAY) {
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++)
+          child_interval<true>(__builtin_fmaf(byte_of(p1.x, ch), sx, gx), __builtin_fmaf(byte_of(p1.y, ch), sy, gy),
+                               __builtin_fmaf(byte_of(p1.z, ch), sz, gz), __builtin_fmaf(byte_of(p1.w, ch), sx, gx),
+                               __builtin_fmaf(byte_of(p2.x, ch), sy, gy), __builtin_fmaf(byte_of(p2.y, ch), sz, gz), 0.0f, o, sl, c.best_t,
+                               tn[ch], tf[ch]);
+      } else {
+        // planes relative to the ray origin in one FMA each: q * step + (org - o)
+        const float rx = gx - o.x, ry = gy - o.y, rz = gz - o.z;
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++)
+          child_interval_rel(__builtin_fmaf(byte_of(p1.x, ch), sx, rx), __builtin_fmaf(byte_of(p1.y, ch), sy, ry),
+                             __builtin_fmaf(byte_of(p1.z, ch), sz, rz), __builtin_fmaf(byte_of(p1.w, ch), sx, rx),
+                             __builtin_fmaf(byte_of(p2.x, ch), sy, ry), __builtin_fmaf(byte_of(p2.y, ch), sz, rz),
+                             half_of(ch < 2 ? p2.z : p2.w, ch & 1), sl, c.best_t, tn[ch], tf[ch]);
+      }
+    } else {
+      ref = reinterpret_cast<const int4*>(nd)[6];
+    }
+    const int refs[4] = {ref.x, ref.y, ref.z, ref.w};
+    if (!PACKED) {
+    } else if (SELECT) {
       const uint32_t sx = sl.sel & 0xFFu, sy = (sl.sel >> 8) & 0xFFu, sz = (sl.sel >> 16) & 0xFFu;
       const float4 nx = *reinterpret_cast<const float4*>(nd + sx);
       const float4 ny = *reinterpret_cast<const float4*>(nd + 16 + sy);
@@ -569,21 +634,12 @@ struct tree_search {
       child_interval_selected(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, sl, c.best_t, tn[1], tf[1]);
       child_interval_selected(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, sl, c.best_t, tn[2], tf[2]);
       child_interval_selected(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, sl, c.best_t, tn[3], tf[3]);
-    } else {
-      // trees read from HBM: the first pieces of the node come from the staging area, the others
-      // from the node itself (both address calculations fold away for trees in LDS)
-      const unsigned char* rest = PACKED ? nd : reinterpret_cast<const unsigned char*>(sv.nodes) + (size_t)cur * sizeof(bvh4_node);
-#define RT_PIECE(i) (*reinterpret_cast<const float4*>((!PACKED && (i) < RT_STAGE_PIECES ? nd : rest) + 16 * (i)))
-      const float4 hiy = RT_PIECE(4);
-      const float4 hiz = RT_PIECE(5);
+    } else {  // trees in LDS with one pad per child box
+      const float4 lox = reinterpret_cast<const float4*>(nd)[0], loy = reinterpret_cast<const float4*>(nd)[1],
+                   loz = reinterpret_cast<const float4*>(nd)[2], hix = reinterpret_cast<const float4*>(nd)[3],
+                   hiy = reinterpret_cast<const float4*>(nd)[4], hiz = reinterpret_cast<const float4*>(nd)[5];
       float4 rmin = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (!PAD_RAY) rmin = RT_PIECE(7);
-      if (!PACKED) stage_wait();
-      const float4 lox = RT_PIECE(0);
-      const float4 loy = RT_PIECE(1);
-      const float4 loz = RT_PIECE(2);
-      const float4 hix = RT_PIECE(3);
-#undef RT_PIECE
+      if (!PAD_RAY) rmin = reinterpret_cast<const float4*>(nd)[7];
       child_interval<PAD_RAY>(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, rmin.x, o, sl, c.best_t, tn[0], tf[0]);
       child_interval<PAD_RAY>(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, rmin.y, o, sl, c.best_t, tn[1], tf[1]);
       child_interval<PAD_RAY>(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, rmin.z, o, sl, c.best_t, tn[2], tf[2]);
