@@ -21,7 +21,7 @@ enum {
 };
 
 #ifndef RT_TRACE_WAVES
-#define RT_TRACE_WAVES 4
+#define RT_TRACE_WAVES 5
 #endif
 #ifndef RT_JOB_CHUNK
 #define RT_JOB_CHUNK 64u   // pixels / jobs a wave takes from the queue per atomic (more when more lanes ask at once)
@@ -252,7 +252,7 @@ struct searcher {
 // them are (or until no lane is traversing); until then the wave keeps taking
 // traversal steps for the others.
 #define RT_PHASE_VOTE 52
-#define RT_TRACE_VOTE 16
+#define RT_TRACE_VOTE 8
 #define RT_LEAF_VOTE 8
 
 // Work items (pixels, rays) come from one global counter.  Same-address atomics
