@@ -244,6 +244,10 @@ struct searcher {
   RT_DEV int node_wanted() const { return ts.cur; }
   RT_DEV void step_leaf(const scene_view& sv, lane_counters& k) { ts.step_leaf(sv, k); }
   RT_DEV void finish(const scene_dev& sc, const scene_view& sv, float& t, int& idx, lane_counters& k) {
+    if (!T::tree) {  // the scan is the search
+      hit_linear<COUNTED>(sv.scan_sph, sc.n_spheres, ts.o, ts.d, t, idx, k);
+      return;
+    }
     ts.finish(sc, sv, t, idx, k);
   }
 };

@@ -269,22 +269,20 @@ __global__ __launch_bounds__(256) void lbvh_collapse_kernel(const float4* leaf_s
 // One thread per 4-wide node: the children's boxes onto a byte grid over their union (bvh4q_node).  Low planes are
 // rounded down and high planes up, checked in double against the decoded value, so that the decoded box holds the
 // child's box.
-#include <hip/hip_fp16.h>
 __global__ __launch_bounds__(256) void lbvh_quantize_kernel(const bvh4_node* nodes, int n_nodes, bvh4q_node* out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_nodes) return;
   const bvh4_node nd = nodes[i];
   bvh4q_node q;
   q.exps = 0u;
-  unsigned short rh[4];
+  float rmin = __builtin_inff();
 #pragma unroll
   for (int s = 0; s < 4; s++) {
     q.ref[s] = nd.ref[s];
-    const float r = nd.ref[s] == RT_REF_EMPTY ? 0.0f : fminf(fmaxf(nd.rmin[s], 0.0f), 65504.0f);  // (a NaN radius: 0)
-    rh[s] = __half_as_ushort(__float2half_rz(r));
+    if (nd.ref[s] != RT_REF_EMPTY) rmin = fminf(rmin, fmaxf(nd.rmin[s], 0.0f));  // (a NaN radius counts as 0)
   }
-  q.rmin_h[0] = (uint32_t)rh[0] | ((uint32_t)rh[1] << 16);
-  q.rmin_h[1] = (uint32_t)rh[2] | ((uint32_t)rh[3] << 16);
+  q.rmin = rmin < __builtin_inff() ? rmin : 0.0f;
+  q.open = 0u;
 #pragma unroll
   for (int a = 0; a < 3; a++) {
     const float* lo = a == 0 ? nd.lox : a == 1 ? nd.loy : nd.loz;
@@ -329,15 +327,10 @@ __global__ __launch_bounds__(256) void lbvh_quantize_kernel(const bvh4_node* nod
         wlo |= (uint32_t)ql << (8 * s);
         whi |= (uint32_t)qh << (8 * s);
       }
-    } else {  // an extent that is not finite: every child passes on this axis
-      org = -3.402823466e38f;
-      e = 127;
-#pragma unroll
-      for (int s = 0; s < 4; s++) {
-        const bool used = nd.ref[s] != RT_REF_EMPTY;
-        wlo |= (uint32_t)(used ? 0 : 255) << (8 * s);
-        whi |= (uint32_t)(used ? 255 : 0) << (8 * s);
-      }
+    } else {  // an extent that is not finite: no grid, every child of the node passes
+      org = 0.0f;
+      e = 0;
+      q.open = 1u;
     }
     q.org[a] = org;
     q.exps |= (uint32_t)(e + 127) << (8 * a);

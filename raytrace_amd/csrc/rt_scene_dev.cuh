@@ -21,19 +21,21 @@ struct __attribute__((aligned(16))) bvh4_node {
 // The same node as trees read from HBM carry it: 64 bytes, what one group of four lanes fetches with one 64-byte
 // access.  The children's planes are bytes on a grid laid over the box of all four: plane = org + q * 2^(e - 127)
 // per axis, low planes rounded down and high planes up at build time, so that a decoded box holds the child's box
-// (whose growing rule then applies unchanged: the decoded box holds every sphere below).  rmin travels as binary16
-// rounded toward zero (a smaller rmin only grows the pad).  An axis whose extent is not finite takes org = -FLT_MAX
-// and the largest step: its planes decode to -FLT_MAX and +infinity, every child passes on that axis.
+// (whose growing rule then applies unchanged: the decoded box holds every sphere below).  One rmin for the node, the
+// smallest radius below any child: the PAD_NODE rule grows the four boxes by one pad, that of the grid's whole
+// extent (farther corner, smaller radius than any child's own: never less than a child's own pad).  A node with
+// an extent that is not finite on some axis has no grid: `open` is set and every child passes.
 //   piece 0: org.x org.y org.z | exps (byte a: biased exponent of the step on axis a)
 //   piece 1: qlo.x[4] | qlo.y[4] | qlo.z[4] | qhi.x[4]      (byte ch of a word: child ch)
-//   piece 2: qhi.y[4] | qhi.z[4] | rmin[0..1] | rmin[2..3]  (binary16 pairs)
+//   piece 2: qhi.y[4] | qhi.z[4] | rmin | open
 //   piece 3: ref[4]
 struct __attribute__((aligned(16))) bvh4q_node {
   float org[3];
   uint32_t exps;
   uint32_t qlo[3];
   uint32_t qhi[3];
-  uint32_t rmin_h[2];
+  float rmin;
+  uint32_t open;
   int32_t ref[4];
 };
 static_assert(sizeof(bvh4q_node) == 64, "one 64-byte access per node");
@@ -108,6 +110,32 @@ struct scene_view {
 // Returns t (-1 or a stuck NaN mean "no hit": the caller tests t > 0.001) and
 // the index that produced it.
 // ---------------------------------------------------------------------------
+// The same scan one sphere at a time, for the rare ray a tree search hands back (finish()): the same accept rule
+// on the same values in the same order, without the block structure and the prefetch registers of hit_linear, which
+// would set the register budget of the tree kernels.
+template <bool COUNTED>
+RT_DEV void hit_linear_lean(const float4* sph, int n, f3 o, f3 d, float& t_out, int& i_out, lane_counters& k) {
+  const float a = dot3(d, d);
+  float best_t = -1.0f;
+  int best_i = -1;
+  RT_COUNT(k, sphere_tests, (uint32_t)n);
+#pragma unroll 1
+  for (int i = 0; i < n; i++) {
+    const float4 s = sph[i];
+    float h, disc;
+    sphere_disc(s.x, s.y, s.z, s.w, o, d, a, h, disc);
+    if (disc >= 0.0f) {
+      const float t = sphere_roots<COUNTED>(h, disc, a, k);
+      if (best_t < 0.0f || (t < best_t && t > 0.001f)) {  // fs:180
+        best_t = t;
+        best_i = i;
+      }
+    }
+  }
+  t_out = best_t;
+  i_out = best_i;
+}
+
 template <bool COUNTED>
 RT_DEV void hit_linear(const float4* sph, int n, f3 o, f3 d, float& t_out, int& i_out, lane_counters& k) {
   const float a = dot3(d, d);
@@ -367,19 +395,7 @@ RT_DEV void child_interval(float lx, float ly, float lz, float hx, float hy, flo
   tf = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), limit);
 }
 
-// The same for a box given relative to the ray origin (a = lo - o, b = hi - o per axis), PAD_NODE rule.
-RT_DEV void child_interval_rel(float ax, float ay, float az, float bx, float by, float bz, float rmin, const slab_consts& s, float limit,
-                               float& tn, float& tf) {
-  const float pad = box_pad(fmaxf(-ax, bx), fmaxf(-ay, by), fmaxf(-az, bz), rmin);
-  const float t0x = (ax - pad) * s.inv_d.x, t1x = (bx + pad) * s.inv_d.x;
-  const float t0y = (ay - pad) * s.inv_d.y, t1y = (by + pad) * s.inv_d.y;
-  const float t0z = (az - pad) * s.inv_d.z, t1z = (bz + pad) * s.inv_d.z;
-  tn = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), RT_T_FLOOR);
-  tf = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), limit);
-}
-
 RT_DEV float byte_of(uint32_t w, int ch) { return (float)((w >> (8 * ch)) & 255u); }
-RT_DEV float half_of(uint32_t w, int hi) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(hi ? w >> 16 : w & 0xFFFFu)); }
 
 // Node fetch for trees read from HBM.  A lane that loads its own 128-byte node with eight 16-byte
 // loads costs the CU's vector cache eight tag look-ups per lane, 512 per wave and step, and that
@@ -608,20 +624,38 @@ struct tree_search {
                                __builtin_fmaf(byte_of(p2.x, ch), sy, gy), __builtin_fmaf(byte_of(p2.y, ch), sz, gz), 0.0f, o, sl, c.best_t,
                                tn[ch], tf[ch]);
       } else {
-        // planes relative to the ray origin in one FMA each: q * step + (org - o)
+        // One pad for the node: farthest corner of the grid's extent (org .. org + 255 steps), the node's rmin.  Folded
+        // with the slab arithmetic into per-node constants, a child's plane parameter is one FMA on its byte:
+        // t = q * (step / d) + (org - o -+ pad) / d.  (The rounding of these products, a few 1e-7 of the distances
+        // involved, is what the pad's linear term is for.)
         const float rx = gx - o.x, ry = gy - o.y, rz = gz - o.z;
+        const float pad = box_pad(fmaxf(-rx, __builtin_fmaf(255.0f, sx, rx)), fmaxf(-ry, __builtin_fmaf(255.0f, sy, ry)),
+                                  fmaxf(-rz, __builtin_fmaf(255.0f, sz, rz)), __uint_as_float(p2.z));
+        const float kx = sx * sl.inv_d.x, ky = sy * sl.inv_d.y, kz = sz * sl.inv_d.z;
+        const float ax = (rx - pad) * sl.inv_d.x, ay = (ry - pad) * sl.inv_d.y, az = (rz - pad) * sl.inv_d.z;
+        const float bx = (rx + pad) * sl.inv_d.x, by = (ry + pad) * sl.inv_d.y, bz = (rz + pad) * sl.inv_d.z;
 #pragma unroll
-        for (int ch = 0; ch < 4; ch++)
-          child_interval_rel(__builtin_fmaf(byte_of(p1.x, ch), sx, rx), __builtin_fmaf(byte_of(p1.y, ch), sy, ry),
-                             __builtin_fmaf(byte_of(p1.z, ch), sz, rz), __builtin_fmaf(byte_of(p1.w, ch), sx, rx),
-                             __builtin_fmaf(byte_of(p2.x, ch), sy, ry), __builtin_fmaf(byte_of(p2.y, ch), sz, rz),
-                             half_of(ch < 2 ? p2.z : p2.w, ch & 1), sl, c.best_t, tn[ch], tf[ch]);
+        for (int ch = 0; ch < 4; ch++) {
+          const float t0x = __builtin_fmaf(byte_of(p1.x, ch), kx, ax), t1x = __builtin_fmaf(byte_of(p1.w, ch), kx, bx);
+          const float t0y = __builtin_fmaf(byte_of(p1.y, ch), ky, ay), t1y = __builtin_fmaf(byte_of(p2.x, ch), ky, by);
+          const float t0z = __builtin_fmaf(byte_of(p1.z, ch), kz, az), t1z = __builtin_fmaf(byte_of(p2.y, ch), kz, bz);
+          tn[ch] = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), RT_T_FLOOR);
+          tf[ch] = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), c.best_t);
+        }
       }
     } else {
       ref = reinterpret_cast<const int4*>(nd)[6];
     }
     const int refs[4] = {ref.x, ref.y, ref.z, ref.w};
     if (!PACKED) {
+      // a node with an extent that is not finite has no grid (bvh4q_node::open): all its children pass
+      if (reinterpret_cast<const uint32_t*>(nd)[11] != 0u) {
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++) {
+          tn[ch] = RT_T_FLOOR;
+          tf[ch] = c.best_t;
+        }
+      }
     } else if (SELECT) {
       const uint32_t sx = sl.sel & 0xFFu, sy = (sl.sel >> 8) & 0xFFu, sz = (sl.sel >> 16) & 0xFFu;
       const float4 nx = *reinterpret_cast<const float4*>(nd + sx);
@@ -752,7 +786,7 @@ struct tree_search {
 
   RT_DEV void finish(const scene_dev& sc, const scene_view& sv, float& t_out, int& i_out, lane_counters& k) {
     if (c.redo()) {
-      hit_linear<COUNTED>(sv.scan_sph, sc.n_spheres, o, d, t_out, i_out, k);
+      hit_linear_lean<COUNTED>(sv.scan_sph, sc.n_spheres, o, d, t_out, i_out, k);
       return;
     }
     t_out = c.best_i >= 0 ? c.best_t : -1.0f;
