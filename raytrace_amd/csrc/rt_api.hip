@@ -740,6 +740,13 @@ int probe_samples(int n_samples, bool swept) {
   n = n < 8 ? 8 : n;
   return n > most ? most : n;
 }
+bool stored_kernel_enabled() {  // RT_STORED_KERNEL=0: every pass in the kernel whose lanes own their pixels (comparison)
+  static bool v = [] {
+    const char* e = getenv("RT_STORED_KERNEL");
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
 bool two_pass_enabled() {
   static bool v = [] {
     const char* e = getenv("RT_TWO_PASS");
@@ -861,6 +868,63 @@ hipError_t launch_render_one(rt_ctx* c, const rt_params* p, hipStream_t st, rend
   return hipGetLastError();
 }
 
+// rt_render_stored_kernel: the search's LDS plus one camera ray in reserve per lane.
+template <int SEARCH>
+size_t stored_lds_bytes(const rt_ctx* c) {
+  return pad16(search_lds_bytes<SEARCH>(counts_of(c))) + (size_t)search_traits<SEARCH>::waves * RT_RESERVE_BYTES;
+}
+
+template <int SEARCH, bool COUNTED>
+hipError_t launch_stored_one(rt_ctx* c, hipStream_t st, render_args a) {
+  using T = search_traits<SEARCH>;
+  const int tw = a.p.tile_x1 - a.p.tile_x0, th = a.vrows;
+  const size_t lds = stored_lds_bytes<SEARCH>(c);
+  a.reserve_offset = (uint32_t)(lds - (size_t)T::waves * RT_RESERVE_BYTES);
+  hipError_t e = allow_lds(rt_render_stored_kernel<SEARCH, COUNTED>, lds);
+  if (e != hipSuccess) return e;
+  int per_cu = 0;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_stored_kernel<SEARCH, COUNTED>, T::threads, lds);
+  if (e != hipSuccess) return e;
+  if (per_cu < 1) per_cu = 1;
+  const long long tiles = (long long)((tw + 7) / 8) * ((th + 7) / 8);
+  long long blocks = (long long)per_cu * c->n_cu;
+  const long long needed = (tiles + T::waves - 1) / T::waves;
+  if (blocks > needed) blocks = needed;
+  if (blocks < 1) blocks = 1;
+  e = attach_overflow<SEARCH>(c, blocks, a.sc);
+  if (e != hipSuccess) return e;
+  rt_render_stored_kernel<SEARCH, COUNTED><<<dim3((unsigned)blocks), T::threads, lds, st>>>(a);
+  return hipGetLastError();
+}
+
+template <int SEARCH>
+hipError_t launch_stored(rt_ctx* c, bool counted, hipStream_t st, const render_args& a) {
+  return counted ? launch_stored_one<SEARCH, true>(c, st, a) : launch_stored_one<SEARCH, false>(c, st, a);
+}
+
+// Whether the uploaded scene's search leaves room in LDS for the reserves of rt_render_stored_kernel.
+bool stored_fits(const rt_ctx* c) {
+  switch (c->search) {
+    case SEARCH_TREE_LDS_RAY: return stored_lds_bytes<SEARCH_TREE_LDS_RAY>(c) <= kMaxLdsBytes;
+    case SEARCH_TREE_LDS_NODE: return stored_lds_bytes<SEARCH_TREE_LDS_NODE>(c) <= kMaxLdsBytes;
+    case SEARCH_TREE_GLB_RAY: return stored_lds_bytes<SEARCH_TREE_GLB_RAY>(c) <= kMaxLdsBytes;
+    case SEARCH_TREE_GLB_NODE: return stored_lds_bytes<SEARCH_TREE_GLB_NODE>(c) <= kMaxLdsBytes;
+    case SEARCH_LINEAR_LDS: return stored_lds_bytes<SEARCH_LINEAR_LDS>(c) <= kMaxLdsBytes;
+    default: return true;
+  }
+}
+
+// Empty reserves that make a refill worth a wave (RT_REFILL_VOTE overrides, for tuning).
+int refill_vote() {
+  static int v = vote_from_env("RT_REFILL_VOTE", RT_REFILL_VOTE);
+  return v;
+}
+
+int refill_min() {
+  static int v = vote_from_env("RT_REFILL_MIN", RT_REFILL_MIN);
+  return v;
+}
+
 template <int SEARCH>
 hipError_t launch_render(rt_ctx* c, const rt_params* p, bool counted, hipStream_t st, const render_args& a) {
   if (p->rng_mode == RT_RNG_XORSHIFT_REF)
@@ -965,6 +1029,24 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       default: return launch_render<SEARCH_LINEAR>(c, rp, counted, c->stream, ra);
     }
   };
+  auto launch_stored_pass = [&](const render_args& ra) -> hipError_t {
+    hipError_t qe = hipMemsetAsync(c->queue.p, 0, sizeof(unsigned long long), c->stream);
+    if (qe != hipSuccess) return qe;
+    switch (c->search) {
+      case SEARCH_TREE_LDS_RAY: return launch_stored<SEARCH_TREE_LDS_RAY>(c, counted, c->stream, ra);
+      case SEARCH_TREE_LDS_NODE: return launch_stored<SEARCH_TREE_LDS_NODE>(c, counted, c->stream, ra);
+      case SEARCH_TREE_GLB_RAY: return launch_stored<SEARCH_TREE_GLB_RAY>(c, counted, c->stream, ra);
+      case SEARCH_TREE_GLB_NODE: return launch_stored<SEARCH_TREE_GLB_NODE>(c, counted, c->stream, ra);
+      case SEARCH_LINEAR_LDS: return launch_stored<SEARCH_LINEAR_LDS>(c, counted, c->stream, ra);
+      default: return launch_stored<SEARCH_LINEAR>(c, counted, c->stream, ra);
+    }
+  };
+  // Passes whose every sample is stored run in the kernel that keeps camera rays in reserve (counter generator; a
+  // bounce limit of zero has no rays to trace; the reserves must fit LDS beside the scene).
+  const bool stored_ok = p->rng_mode == RT_RNG_COUNTER && p->bounce_limit > 0u && stored_fits(c) && stored_kernel_enabled();
+  a.reserve_offset = 0;
+  a.refill_vote = refill_vote();
+  a.refill_min = refill_min();
   a.pass = 0;
   a.sweeps = 1;
   a.jobs = nullptr;
@@ -991,7 +1073,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   // radiance summed in order afterwards) — a pixel per job would end with the expensive pixels' lanes working alone.
   size_t split_budget, probe_budget;
   scratch_budgets(c, split_budget, probe_budget);
-  bool whole_in_sweeps = !two_pass && two_pass_enabled() && p->rng_mode == RT_RNG_COUNTER && probe_sweeps() > 1 &&
+  bool whole_in_sweeps = !two_pass && two_pass_enabled() && stored_ok && probe_sweeps() > 1 &&
                          n_samples >= 2 && n_rect >= 16384 &&
                          n_rect * stored_samples(n_samples) * kSampleFloats * sizeof(float) <= probe_budget;
   // (a store that cannot be had costs speed, never the frame: the plain schedules below need none)
@@ -1002,11 +1084,11 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
     sw.sweeps = probe_sweeps() < n_samples ? probe_sweeps() : n_samples;
     sw.split_samples = reinterpret_cast<float4*>(c->probe_samples.p);
     sw.main_samples = n_samples;
-    e = launch(sw, p);
+    e = launch_stored_pass(sw);
     if (e == hipSuccess) {
       rt_probe_sum_kernel<<<(unsigned)((n_rect + 255) / 256), 256, 0, c->stream>>>(
           (uint32_t)n_rect, reinterpret_cast<const float4*>(c->probe_samples.p), n_samples, p->tile_x0, p->tile_y0, tw, p->width,
-          p->strip_count, p->strip_index, c->accum(), nullptr, nullptr);
+          p->strip_count, p->strip_index, c->accum(), nullptr, nullptr, nullptr);
       e = hipGetLastError();
     }
   } else if (!two_pass) {
@@ -1029,7 +1111,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
     probe.carry_rng = c->carry_rng.p;
     probe.carry_cost = c->carry_cost.p;
     // Counter RNG: the probe runs in sweeps (see render_args), its samples in a buffer of their own.
-    bool swept = p->rng_mode == RT_RNG_COUNTER && probe_sweeps() > 1;
+    bool swept = stored_ok && probe_sweeps() > 1;
     int n_probe = probe_samples(n_samples, swept);
     if (swept && (n_rect * stored_samples(n_probe) * kSampleFloats * sizeof(float) > probe_budget ||
                   c->probe_samples.fit(n_rect * stored_samples(n_probe) * kSampleFloats) != hipSuccess)) {
@@ -1039,17 +1121,16 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
     const int sweeps = probe_sweeps() < n_probe ? probe_sweeps() : n_probe;
     probe.p.sample_end = p->sample_begin + n_probe;
     if (swept) {
-      HIP_TRY(hipMemsetAsync(c->carry_cost.p, 0, n_rect * sizeof(uint32_t), c->stream));
       probe.pass = 3;
       probe.sweeps = sweeps;
       probe.split_samples = reinterpret_cast<float4*>(c->probe_samples.p);
       probe.main_samples = n_probe;
     }
-    e = launch(probe, p);
+    e = swept ? launch_stored_pass(probe) : launch(probe, p);
     if (e == hipSuccess && swept) {
       rt_probe_sum_kernel<<<(unsigned)((n_rect + 255) / 256), 256, 0, c->stream>>>(
           (uint32_t)n_rect, reinterpret_cast<const float4*>(c->probe_samples.p), n_probe, p->tile_x0, p->tile_y0, tw, p->width,
-          p->strip_count, p->strip_index, c->accum(), c->carry_colour.p, c->carry_rng.p);
+          p->strip_count, p->strip_index, c->accum(), c->carry_colour.p, c->carry_rng.p, c->carry_cost.p);
       e = hipGetLastError();
       probe.pass = 1;  // what follows copies `probe` for the main pass
       probe.sweeps = 1;
@@ -1089,6 +1170,8 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       // the store of the cut pixels' samples: when the device cannot give it, fewer pixels are cut, in the end none
       while (max_split > 0 && c->split_samples.fit((size_t)max_split * stored_samples(main_samples) * kSampleFloats) != hipSuccess) max_split /= 2;
       const int splittable = max_split > 0 ? 1 : 0;
+      // every pixel has a row in the store: the main pass too runs in the kernel with rays in reserve
+      const int all_rows = splittable && max_split >= n && stored_ok ? 1 : 0;
       HIP_TRY(c->plan_parts.resize(n));
       HIP_TRY(c->plan_first.resize(n));
       HIP_TRY(c->plan_counts.resize(1));
@@ -1106,7 +1189,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       HIP_TRY(rocprim::exclusive_scan(c->scan_temp.p, scan_bytes, c->plan_parts.p, c->plan_first.p, 0u, n, rocprim::plus<uint32_t>(),
                                       c->stream));
       rt_plan_jobs_kernel<<<grid, 256, 0, c->stream>>>(c->order_idx.p, c->plan_parts.p, c->plan_first.p, n, main_begin,
-                                                      p->sample_end, c->plan_jobs.p, c->plan_counts.p);
+                                                      p->sample_end, all_rows, c->plan_jobs.p, c->plan_counts.p);
       HIP_TRY(hipGetLastError());
       render_args mainp = probe;
       mainp.pass = 2;
@@ -1117,12 +1200,12 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       mainp.split_samples = reinterpret_cast<float4*>(c->split_samples.p);
       mainp.main_samples = main_samples;
       mainp.split_rows = n < max_split ? n : max_split;
-      e = launch(mainp, p);
+      e = all_rows ? launch_stored_pass(mainp) : launch(mainp, p);
       if (e == hipSuccess && splittable) {
         const uint32_t cand = n < max_split ? n : max_split;
         rt_sum_split_kernel<<<(cand + 255) / 256, 256, 0, c->stream>>>(c->order_idx.p, c->plan_parts.p, cand, c->carry_colour.p,
                                                                       reinterpret_cast<const float4*>(c->split_samples.p), main_samples, cand, p->tile_x0, p->tile_y0,
-                                                                      tw, p->width, p->strip_count, p->strip_index, c->accum());
+                                                                      tw, p->width, p->strip_count, p->strip_index, all_rows, c->accum());
         e = hipGetLastError();
       }
     }

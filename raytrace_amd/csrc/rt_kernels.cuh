@@ -38,7 +38,7 @@ struct search_traits {
   static constexpr bool pad_ray = SEARCH == SEARCH_TREE_LDS_RAY || SEARCH == SEARCH_TREE_GLB_RAY;
   static constexpr int waves = lds ? 16 : 4;       // waves per workgroup
   static constexpr int threads = waves * 64;
-  static constexpr int stack = lds ? 16 : 8;       // entries per lane kept in LDS
+  static constexpr int stack = lds ? 12 : 8;       // entries per lane kept in LDS
   // per wave: one word per entry and lane; above the last row, three rows of slack for trees in LDS (a node step
   // stores three keys above the top whatever it pushes), one row for the others (the sink of stores that do not fit)
   static constexpr int stack_words = !tree ? 0 : (stack + (lds ? 3 : 1)) * 64;
@@ -86,6 +86,9 @@ RT_DEV int real_row(int vy, int tile_y0, int strip_count, int strip_index) {
 struct render_args {
   rt_params p;                 // seed_tex inside is a host pointer and is not used on the device
   int vrows;                   // rows of this call's share of the tile (virtual rows, see real_row)
+  uint32_t reserve_offset;     // rt_render_stored_kernel: where the lanes' camera rays in reserve lie in the dynamic LDS
+  int refill_vote;             // ... and how many empty reserves make a refill worth a wave,
+  int refill_min;              // ... or at least warranted when a lane has run out of rays
   scene_dev sc;
   float* accum;                // width*height*3 radiance sums
   const uint32_t* seed_tex;    // device copy of p.seed_tex, or null
@@ -306,6 +309,83 @@ RT_DEV Q take_items(bool need, Q* queue, Q& pool_next, Q& pool_end) {
 #define RT_CLK_STOP(i) do {} while (0)
 #endif
 
+// bounce() for a lane whose search is over (fs:201-223): hit record and material scatter, or the sky.  Returns
+// whether the path goes on; if so, srch.ts.o / srch.ts.d hold the next segment's ray.  alb is the path's throughput
+// and, when the path ends, its radiance.
+template <int SEARCH, int RNG, bool COUNTED>
+RT_DEV bool shade_finished(searcher<SEARCH, COUNTED>& srch, const scene_dev& sc, const scene_view& sv, uint32_t bounce_limit, f3& alb,
+                           uint32_t& rng, uint32_t& count, lane_counters& k) {
+  float t;
+  int idx;
+  srch.finish(sc, sv, t, idx, k);
+  const f3 o = srch.ts.o;
+  f3 d = srch.ts.d;
+  bool cont;
+  f3 next_o = o;
+  if (t > 0.001f) {  // fs:186-196
+    RT_COUNT(k, hits, 1);
+    const float4 sp = sv.sph[idx];
+    hit_rec h;
+    h.point = o + d * t;
+    h.normal = sv.inv_r[idx] * (h.point - mk3(sp.x, sp.y, sp.z));
+    h.interior = false;
+    if (dot3(h.normal, d) >= 0.0f) {
+      h.normal = -h.normal;
+      h.interior = true;
+    }
+    h.mat = sv.sph_mat[idx];
+    const float4 ma = sv.mat_a[h.mat];
+    const int type = sv.mat_type[h.mat];
+    next_o = h.point;  // fs:211-212
+    count = count + 1u;
+    cont = shade_hit<RNG, COUNTED>(h, type, ma.w, mk3(ma.x, ma.y, ma.z), sc.noise, d, alb, rng, k);
+  } else {  // fs:217-218
+    alb = sky_radiance(d, alb);
+    cont = false;
+    RT_COUNT(k, sky, 1);
+  }
+  if (cont && count >= bounce_limit) {  // the next bounce() would stop here, fs:203-205
+    alb = mk3(0.0f, 0.0f, 0.0f);
+    cont = false;
+    RT_COUNT(k, limit_hits, 1);
+  }
+  if (cont) {
+    srch.ts.o = next_o;
+    srch.ts.d = d;
+  }
+  return cont;
+}
+
+// The camera block of the shader's main (fs:117-131) for sample `rng` is keyed for: jitter, point on the viewport,
+// origin on the defocus disk.
+struct camera_consts {
+  f3 delta_u, delta_v, cam, vtl, ddu, ddv;
+  float defocus_angle;
+};
+RT_DEV camera_consts load_camera(const rt_params& P) {
+  camera_consts c;
+  c.delta_u = mk3(P.delta_u[0], P.delta_u[1], P.delta_u[2]);
+  c.delta_v = mk3(P.delta_v[0], P.delta_v[1], P.delta_v[2]);
+  c.cam = mk3(P.camera_origin[0], P.camera_origin[1], P.camera_origin[2]);
+  c.vtl = mk3(P.viewport_top_left[0], P.viewport_top_left[1], P.viewport_top_left[2]);
+  c.ddu = mk3(P.defocus_disk_u[0], P.defocus_disk_u[1], P.defocus_disk_u[2]);
+  c.ddv = mk3(P.defocus_disk_v[0], P.defocus_disk_v[1], P.defocus_disk_v[2]);
+  c.defocus_angle = P.defocus_angle;
+  return c;
+}
+template <int RNG, bool COUNTED>
+RT_DEV void camera_ray(const camera_consts& C, int x, int y, uint32_t& rng, f3& ro, f3& rd, lane_counters& k) {
+  const float jx = rng_float<RNG>(rng) - 0.5f;
+  const float jy = rng_float<RNG>(rng) - 0.5f;
+  const f3 frag = C.vtl + ((float)x + jx) * C.delta_u + ((float)y + jy) * C.delta_v;
+  ro = C.cam;
+  if (!(C.defocus_angle <= 0.0f)) {
+    const f3 disk = random_unit_disk<RNG, COUNTED>(rng, k);
+    ro = C.cam + disk.x * C.ddu + disk.y * C.ddv;
+  }
+  rd = frag - ro;
+}
+
 // Persistent lanes with phase voting.
 //
 // The launch holds as many workgroups as the chip keeps resident.  Every lane
@@ -338,12 +418,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
   const uint32_t total_items = A.pass == 2 ? *A.n_jobs : (A.pass == 3 ? tile_items * (uint32_t)A.sweeps : tile_items);
 
   lane_counters k = {};
-  const f3 delta_u = mk3(P.delta_u[0], P.delta_u[1], P.delta_u[2]);
-  const f3 delta_v = mk3(P.delta_v[0], P.delta_v[1], P.delta_v[2]);
-  const f3 cam = mk3(P.camera_origin[0], P.camera_origin[1], P.camera_origin[2]);
-  const f3 vtl = mk3(P.viewport_top_left[0], P.viewport_top_left[1], P.viewport_top_left[2]);
-  const f3 ddu = mk3(P.defocus_disk_u[0], P.defocus_disk_u[1], P.defocus_disk_u[2]);
-  const f3 ddv = mk3(P.defocus_disk_v[0], P.defocus_disk_v[1], P.defocus_disk_v[2]);
+  const camera_consts C = load_camera(P);
 
   searcher<SEARCH, COUNTED> srch;
   srch.ref_mask = sc.ref_mask;
@@ -423,45 +498,9 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
     bool start_segment = false;
     if (ready && pending) {  // the search for the current segment is over: bounce(), fs:207-219
       pending = false;
-      float t;
-      int idx;
-      srch.finish(sc, sv, t, idx, k);
-      const f3 o = srch.ts.o;
-      f3 d = srch.ts.d;
-      bool cont;
-      f3 next_o = o;
-      if (t > 0.001f) {  // fs:186-196
-        RT_COUNT(k, hits, 1);
-        const float4 sp = sv.sph[idx];
-        hit_rec h;
-        h.point = o + d * t;
-        h.normal = sv.inv_r[idx] * (h.point - mk3(sp.x, sp.y, sp.z));
-        h.interior = false;
-        if (dot3(h.normal, d) >= 0.0f) {
-          h.normal = -h.normal;
-          h.interior = true;
-        }
-        h.mat = sv.sph_mat[idx];
-        const float4 ma = sv.mat_a[h.mat];
-        const int type = sv.mat_type[h.mat];
-        next_o = h.point;  // fs:211-212
-        count = count + 1u;
-        cont = shade_hit<RNG, COUNTED>(h, type, ma.w, mk3(ma.x, ma.y, ma.z), sc.noise, d, alb, rng, k);
-        RT_CLK_STOP(1);
-      } else {  // fs:217-218
-        alb = sky_radiance(d, alb);
-        cont = false;
-        RT_COUNT(k, sky, 1);
-        RT_CLK_STOP(2);
-      }
-      if (cont && count >= P.bounce_limit) {  // the next bounce() would stop here, fs:203-205
-        alb = mk3(0.0f, 0.0f, 0.0f);
-        cont = false;
-        RT_COUNT(k, limit_hits, 1);
-      }
+      const bool cont = shade_finished<SEARCH, RNG, COUNTED>(srch, sc, sv, P.bounce_limit, alb, rng, count, k);
+      RT_CLK_STOP(1);
       if (cont) {
-        srch.ts.o = next_o;
-        srch.ts.d = d;
         start_segment = true;
       } else {  // fs:132: colour += raycast(...)
         add_sample();
@@ -531,14 +570,8 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       RT_CLK_STOP(3);
       if (have && !alive) {  // fs:117-131: next camera sample of this pixel
         if (RNG == RT_RNG_COUNTER) rng = counter_key(P.seed, pixel, (uint32_t)s);
-        const float jx = rng_float<RNG>(rng) - 0.5f;
-        const float jy = rng_float<RNG>(rng) - 0.5f;
-        const f3 frag = vtl + ((float)x + jx) * delta_u + ((float)y + jy) * delta_v;
-        f3 ro = cam;
-        if (!(P.defocus_angle <= 0.0f)) {
-          const f3 rd = random_unit_disk<RNG, COUNTED>(rng, k);
-          ro = cam + rd.x * ddu + rd.y * ddv;
-        }
+        f3 ro, rdir;
+        camera_ray<RNG, COUNTED>(C, x, y, rng, ro, rdir, k);
         alb = mk3(1.0f, 1.0f, 1.0f);
         count = 0;
         alive = true;
@@ -552,7 +585,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
           if (s >= s_end) close_pixel();
         } else {
           srch.ts.o = ro;
-          srch.ts.d = frag - ro;
+          srch.ts.d = rdir;
           start_segment = true;
         }
       }
@@ -576,6 +609,168 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
   }
   k.hits = k.sky = k.lambertian = k.metallic = k.dialectric = k.perlin = k.unit_tries = k.disk_tries = k.limit_hits = 0;
 #endif
+  flush_counters<COUNTED>(A.counters, k);
+}
+
+// ---- the render kernel for passes whose every sample is stored -----------------
+// When every sample's radiance goes to the per-sample store (a pass in sweeps; a main pass whose every pixel has a
+// row), a path owes nothing to the lane that runs it: no pixel sum lives in registers.  That is used to take camera
+// rays out of the path phase.  In the kernel above a path that ends is followed, in the same phase, by the next
+// sample's camera ray — counter key, jitter, the defocus disk's rejection loop, some 200 instructions — issued for
+// the two lanes in five whose path has just ended.  Here every lane keeps ONE camera ray in reserve in LDS (32 bytes:
+// origin, direction, generator state, the slot its sample goes to).  A lane whose path ends takes its reserve with
+// two LDS reads and goes on; the reserves are refilled, for all lanes that have used theirs, when `refill_vote` of
+// them are empty (or a lane needs one and has none), i.e. by a nearly full wave.  A lane walks its job's samples in
+// order either way, and a sample's value does not depend on when its ray was made (counter generator), so the
+// image's bits are those of the kernel above.  The probe's cost measure travels in the record's fourth word.
+#define RT_REFILL_VOTE 40
+#define RT_REFILL_MIN 16
+#define RT_RESERVE_BYTES 2048  // per wave: two rows of 64 float4
+
+template <int SEARCH, bool COUNTED>
+__global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARCH>::render_waves_per_simd) void rt_render_stored_kernel(const render_args A) {
+  constexpr int RNG = RT_RNG_COUNTER;
+  const rt_params& P = A.p;
+  const scene_dev& sc = A.sc;
+  scene_view sv;
+  uint32_t* stack_col;
+  uint32_t stage;
+  search_setup<SEARCH>(sc, sv, stack_col, stage);
+  float4* reserve = reinterpret_cast<float4*>(rt_lds + A.reserve_offset) + (threadIdx.x >> 6) * (RT_RESERVE_BYTES / 16) + (threadIdx.x & 63);
+
+  const int tw = P.tile_x1 - P.tile_x0, th = A.vrows;
+  const int tiles_x = (tw + 7) >> 3, tiles_y = (th + 7) >> 3;
+  const uint32_t tile_items = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
+  const uint32_t total_items = A.pass == 2 ? *A.n_jobs : tile_items * (uint32_t)A.sweeps;
+  const size_t rows = A.pass == 3 ? (size_t)tw * (size_t)th : (size_t)A.split_rows;
+
+  lane_counters k = {};
+  const camera_consts C = load_camera(P);
+  searcher<SEARCH, COUNTED> srch;
+  srch.ref_mask = sc.ref_mask;
+  srch.reset();
+  bool alive = false, pending = false;       // a path is in flight; its finished search waits to be shaded
+  bool reserve_full = false;                 // the lane's reserve holds a camera ray
+  bool job_left = false, jobs_done = false;  // the lane's job has samples left; the queue is dry
+  bool done = P.sample_end <= P.sample_begin;
+  int jx = 0, jy = 0, js = 0, js_end = 0;    // the job: pixel, next sample to make a ray for, end
+  uint32_t jrow = 0, jpixel = 0;             // its row in the store; its pixel index
+  uint32_t rng = 0, count = 0, cur_slot = 0, path_segments = 0;
+  f3 alb = mk3(0.0f, 0.0f, 0.0f);
+  uint32_t pool_next = 0, pool_end = 0;
+
+  while (true) {
+    const unsigned long long m_live = __ballot(!done);
+    if (m_live == 0ull) break;
+    while (search_traits<SEARCH>::tree) {
+      const unsigned long long m_trav = __ballot(srch.active());
+      if (m_trav == 0ull || __popcll(m_live & ~m_trav) >= A.vote) break;
+      const bool node_lane = srch.node_ready(), leaf_lane = srch.has_leaf();
+      if (srch.leaf_steps && (__ballot(node_lane) == 0ull || __popcll(__ballot(leaf_lane)) >= A.leaf_vote)) {
+        RT_COUNT(k, leaf_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
+        RT_COUNT(k, leaf_lane_steps, leaf_lane ? 1u : 0u);
+        if (leaf_lane) srch.step_leaf(sv, k);
+      } else {
+        RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
+        RT_COUNT(k, trav_lane_steps, node_lane ? 1u : 0u);
+        uint32_t staged = 0u;
+        if (search_traits<SEARCH>::staged) staged = stage_nodes(sv.qnodes, node_lane ? srch.node_wanted() : -1, stage);
+        if (node_lane) srch.step_node(sv, stack_col, staged, k);
+      }
+    }
+    RT_COUNT(k, path_wave_phases, (threadIdx.x & 63) == 0 ? 1u : 0u);
+    const bool ready = !(srch.active() || done);
+    RT_COUNT(k, path_lane_phases, ready ? 1u : 0u);
+
+    bool start_segment = false;
+    if (ready && pending) {
+      pending = false;
+      if (shade_finished<SEARCH, RNG, COUNTED>(srch, sc, sv, P.bounce_limit, alb, rng, count, k)) {
+        start_segment = true;
+      } else {  // fs:132: the sample's radiance, and what the path cost
+        A.split_samples[cur_slot] = make_float4(alb.x, alb.y, alb.z, __uint_as_float(path_segments));
+        alive = false;
+      }
+    }
+    // a lane without a path takes the ray it holds in reserve
+    auto take_reserve = [&]() {
+      const float4 r0 = reserve[0], r1 = reserve[64];
+      srch.ts.o = mk3(r0.x, r0.y, r0.z);
+      srch.ts.d = mk3(r1.x, r1.y, r1.z);
+      rng = __float_as_uint(r0.w);
+      cur_slot = __float_as_uint(r1.w);
+      alb = mk3(1.0f, 1.0f, 1.0f);
+      count = 0;
+      path_segments = 0;
+      alive = true;
+      reserve_full = false;
+      start_segment = true;
+      RT_COUNT(k, paths, 1);
+    };
+    if (ready && !alive && reserve_full) take_reserve();
+    // Refill the reserves: worth a wave when `refill_vote` are empty; when a lane is out of rays, already at
+    // `refill_min` empty ones (below that the lane waits for company) — or at once if no lane of the wave would
+    // be traversing meanwhile.
+    const bool fill = !reserve_full && !jobs_done && !done;
+    const unsigned long long m_fill = __ballot(fill);
+    const int n_fill = __popcll(m_fill);
+    const bool starving = __ballot(fill && ready && !alive) != 0ull;
+    if (m_fill != 0ull && (n_fill >= A.refill_vote || (starving && (n_fill >= A.refill_min || __ballot(srch.active() || start_segment) == 0ull)))) {
+      const uint32_t item = take_items<unsigned int, RT_JOB_CHUNK>(fill && !job_left, A.queue, pool_next, pool_end);
+      if (fill) {
+        if (!job_left) {
+          if (item >= total_items) {
+            jobs_done = true;
+          } else {
+            int vy;
+            uint32_t rect_pixel;
+            if (A.pass == 2) {
+              const uint4 job = A.jobs[item];
+              rect_pixel = job.x;
+              jx = P.tile_x0 + (int)(rect_pixel % (uint32_t)tw);
+              vy = (int)(rect_pixel / (uint32_t)tw);
+              js = (int)job.y;
+              js_end = (int)job.z;
+              jrow = job.w;
+            } else {  // sweep q takes the q-th part of every pixel's samples
+              const uint32_t sweep = item / tile_items, it = item - sweep * tile_items;
+              // (32-bit arithmetic: the host runs a pass in sweeps only over fewer than 2^24 samples, in at most 64 sweeps)
+              const uint32_t n_all = (uint32_t)(P.sample_end - P.sample_begin);
+              js = P.sample_begin + (int)(n_all * sweep / (uint32_t)A.sweeps);
+              js_end = P.sample_begin + (int)((n_all * sweep + n_all) / (uint32_t)A.sweeps);
+              const uint32_t tile = it >> 6, within = it & 63u;
+              jx = P.tile_x0 + (int)(tile % (uint32_t)tiles_x) * 8 + (int)(within & 7u);
+              vy = (int)(tile / (uint32_t)tiles_x) * 8 + (int)(within >> 3);
+              rect_pixel = (uint32_t)vy * (uint32_t)tw + (uint32_t)(jx - P.tile_x0);
+              jrow = rect_pixel;
+            }
+            jy = real_row(vy, P.tile_y0, P.strip_count, P.strip_index);
+            jpixel = (uint32_t)jy * (uint32_t)P.width + (uint32_t)jx;
+            job_left = jx < P.tile_x1 && vy < th && js < js_end;
+          }
+        }
+        if (job_left) {  // fs:117-131 for the job's next sample, into the reserve
+          uint32_t r = counter_key(P.seed, jpixel, (uint32_t)js);
+          f3 ro, rd;
+          camera_ray<RNG, COUNTED>(C, jx, jy, r, ro, rd, k);
+          const uint32_t slot = (uint32_t)sample_slot((uint32_t)(js - P.sample_begin), (size_t)jrow, rows);
+          reserve[0] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(r));
+          reserve[64] = make_float4(rd.x, rd.y, rd.z, __uint_as_float(slot));
+          reserve_full = true;
+          js++;
+          job_left = js < js_end;
+        }
+      }
+      if (ready && !alive && reserve_full) take_reserve();
+    }
+    if (ready && !alive && !reserve_full && jobs_done) done = true;  // no path, no reserve, no job: the lane is through
+    if (start_segment) {
+      RT_COUNT(k, segments, 1);
+      path_segments++;
+      srch.begin(sc, sv, srch.ts.o, srch.ts.d, k);
+      pending = true;
+    }
+  }
   flush_counters<COUNTED>(A.counters, k);
 }
 
@@ -613,7 +808,7 @@ __global__ __launch_bounds__(256) void rt_plan_count_kernel(const uint32_t* cost
 
 // first[i] = exclusive prefix sum of parts.  Writes the jobs of pixel i and, from the last pixel, the job count.
 __global__ __launch_bounds__(256) void rt_plan_jobs_kernel(const uint32_t* order, const uint32_t* parts, const uint32_t* first,
-                                                          uint32_t n, int sample_begin, int sample_end, uint4* jobs,
+                                                          uint32_t n, int sample_begin, int sample_end, int all_rows, uint4* jobs,
                                                           uint32_t* n_jobs) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -622,7 +817,7 @@ __global__ __launch_bounds__(256) void rt_plan_jobs_kernel(const uint32_t* order
   for (uint32_t j = 0; j < k; j++) {
     const int s0 = sample_begin + (int)(((long long)samples * j) / k);
     const int s1 = sample_begin + (int)(((long long)samples * (j + 1)) / k);
-    jobs[base + j] = make_uint4(order[i], (uint32_t)s0, (uint32_t)s1, k > 1 ? i : RT_JOB_WHOLE);
+    jobs[base + j] = make_uint4(order[i], (uint32_t)s0, (uint32_t)s1, (k > 1 || all_rows) ? i : RT_JOB_WHOLE);
   }
   if (i == n - 1) *n_jobs = base + k;
 }
@@ -632,9 +827,9 @@ __global__ __launch_bounds__(256) void rt_plan_jobs_kernel(const uint32_t* order
 __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order, const uint32_t* parts, uint32_t n_candidates,
                                                           const float* carry_colour, const float4* split_samples, int samples,
                                                           uint32_t n_rows, int tile_x0, int tile_y0, int tile_w, int width,
-                                                          int strip_count, int strip_index, float* accum) {
+                                                          int strip_count, int strip_index, int all_rows, float* accum) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_candidates || parts[i] <= 1u) return;
+  if (i >= n_candidates || (!all_rows && parts[i] <= 1u)) return;
   const uint32_t rect_pixel = order[i];
   f3 colour = mk3(carry_colour[3 * (size_t)rect_pixel], carry_colour[3 * (size_t)rect_pixel + 1], carry_colour[3 * (size_t)rect_pixel + 2]);
   for (int s = 0; s < samples; s++) {  // consecutive threads read consecutive lines of a group's plane
@@ -654,16 +849,19 @@ __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order
 // image (a frame rendered in sweeps as a whole).
 __global__ __launch_bounds__(256) void rt_probe_sum_kernel(uint32_t n_rect, const float4* probe_samples, int n_probe, int tile_x0,
                                                           int tile_y0, int tile_w, int width, int strip_count, int strip_index,
-                                                          float* accum, float* carry_colour, uint32_t* carry_rng) {
+                                                          float* accum, float* carry_colour, uint32_t* carry_rng, uint32_t* record_cost) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_rect) return;
   const int x = tile_x0 + (int)(i % (uint32_t)tile_w), y = real_row((int)(i / (uint32_t)tile_w), tile_y0, strip_count, strip_index);
   float* base = accum + 3 * ((size_t)y * (size_t)width + (size_t)x);
   f3 colour = mk3(base[0], base[1], base[2]);
+  uint32_t cost = 0u;
   for (int s = 0; s < n_probe; s++) {  // consecutive threads read consecutive lines of a group's plane
     const float4 v = probe_samples[sample_slot((uint32_t)s, i, n_rect)];
     colour = colour + mk3(v.x, v.y, v.z);
+    cost += __float_as_uint(v.w);
   }
+  if (record_cost) record_cost[i] = cost;  // (records written by rt_render_stored_kernel carry the segments their path took)
   float* dst = carry_colour ? carry_colour + 3 * (size_t)i : base;
   dst[0] = colour.x;
   dst[1] = colour.y;
