@@ -604,6 +604,17 @@ int choose_search(const rt_ctx* c) {
   return pad_ray ? SEARCH_TREE_GLB_RAY : SEARCH_TREE_GLB_NODE;
 }
 
+const char* stored_name(int search) {
+  switch (search) {
+    case SEARCH_LINEAR: return "rt_render_stored_kernel<linear>";
+    case SEARCH_LINEAR_LDS: return "rt_render_stored_kernel<linear,lds>";
+    case SEARCH_TREE_LDS_RAY: return "rt_render_stored_kernel<lbvh4,lds,pad_ray>";
+    case SEARCH_TREE_LDS_NODE: return "rt_render_stored_kernel<lbvh4,lds,pad_node>";
+    case SEARCH_TREE_GLB_RAY: return "rt_render_stored_kernel<lbvh4,hbm,pad_ray>";
+    default: return "rt_render_stored_kernel<lbvh4,hbm,pad_node>";
+  }
+}
+
 const char* search_name(int search, bool render) {
   switch (search) {
     case SEARCH_LINEAR: return render ? "rt_render_kernel<linear>" : "rt_trace_kernel<linear>";
@@ -1017,7 +1028,9 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   const int tw = p->tile_x1 - p->tile_x0, th = share_rows(p);
   a.vrows = th;
   if (tw == 0 || th == 0 || p->sample_end == p->sample_begin) return RT_OK;
+  bool used_stored = false;  // the kernel the frame's last (and longest) pass ran in
   auto launch = [&](const render_args& ra, const rt_params* rp) -> hipError_t {
+    used_stored = false;
     hipError_t qe = hipMemsetAsync(c->queue.p, 0, sizeof(unsigned long long), c->stream);
     if (qe != hipSuccess) return qe;
     switch (c->search) {
@@ -1030,6 +1043,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
     }
   };
   auto launch_stored_pass = [&](const render_args& ra) -> hipError_t {
+    used_stored = true;
     hipError_t qe = hipMemsetAsync(c->queue.p, 0, sizeof(unsigned long long), c->stream);
     if (qe != hipSuccess) return qe;
     switch (c->search) {
@@ -1211,7 +1225,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
     }
   }
   if (e != hipSuccess) return fail(RT_ERR_DEVICE, "render launch: %s", hipGetErrorString(e));
-  c->last_kernel = search_name(c->search, true);
+  c->last_kernel = used_stored ? stored_name(c->search) : search_name(c->search, true);
   HIP_TRY(hipEventRecord(c->ev_k1, c->stream));
   c->have_kernel_time = true;
   return RT_OK;

@@ -14,7 +14,7 @@ import csv, json, os, sys
 def timed_step_rows(path, counter):
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    last_counted = max((i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(("void rt_render_kernel", "void rt_trace_kernel")) and ", true>(" in r["Kernel_Name"]), default=-1)
+    last_counted = max((i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(("void rt_render_kernel", "void rt_render_stored_kernel", "void rt_trace_kernel")) and ", true>(" in r["Kernel_Name"]), default=-1)
     return rows[last_counted + 1:]
 
 def main():
@@ -42,6 +42,13 @@ def main():
             "per_kernel_kib_fetch_write": {k: v for k, v in per_kernel.items()},
             "source": f"rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE / --pmc WRITE_SIZE, bench.py --steps 1 --warmup 0, timed step only",
         }
+    import datetime, subprocess
+    try:
+        commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=os.path.dirname(os.path.abspath(__file__))).decode().strip()
+    except Exception:
+        commit = "?"
+    out["_meta"] = {"date": datetime.date.today().isoformat(), "commit": commit,
+                    "command": "tools/profile_round.sh (rocprofv3 --pmc passes of bench.py --steps 1 --warmup 0 --no-extras --no-cpu-baseline)"}
     print(json.dumps(out, indent=1))
 
 main()

@@ -9,14 +9,14 @@ out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 run() { echo "== $*"; "$@" || { echo "FAILED: $*"; exit 1; }; }
-run timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c2_lbvh -o t -- python3 $root/bench.py > $out/bench_c2_lbvh.json 2> $out/bench_c2_lbvh.err
-run timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c2_linear -o t -- python3 $root/bench.py --accel linear --steps 3 --no-cpu-baseline > $out/bench_c2_linear.json 2> $out/bench_c2_linear.err
+run timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c2_lbvh -o t -- python3 $root/bench.py --no-extras > $out/bench_c2_lbvh.json 2> $out/bench_c2_lbvh.err
+run timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c2_linear -o t -- python3 $root/bench.py --accel linear --steps 3 --no-cpu-baseline --no-extras > $out/bench_c2_linear.json 2> $out/bench_c2_linear.err
 run timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_c4 -o t -- python3 $root/bench.py --config c4 --steps 3 > $out/bench_c4.json 2> $out/bench_c4.err
 run timeout -k 10 200 python3 $root/bench.py --config c1 --steps 20 > $out/bench_c1.json 2> $out/bench_c1.err
 run timeout -k 10 300 python3 $root/bench.py --config c3 --steps 3 > $out/bench_c3.json 2> $out/bench_c3.err
 for w in "c2_lbvh --steps 1 --warmup 0" "c2_linear --accel linear --steps 1 --warmup 0" "c4 --config c4 --steps 1 --warmup 0" "c3 --config c3 --steps 1 --warmup 0"; do
   set -- $w; name=$1; shift
-  run timeout -s KILL 200 rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $out/pmc_$name -o fetch -- python3 $root/bench.py "$@" --no-cpu-baseline > $out/pmc_$name.fetch.json 2> $out/pmc_$name.fetch.err
-  run timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_$name -o write -- python3 $root/bench.py "$@" --no-cpu-baseline > $out/pmc_$name.write.json 2> $out/pmc_$name.write.err
+  run timeout -s KILL 200 rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $out/pmc_$name -o fetch -- python3 $root/bench.py "$@" --no-cpu-baseline --no-extras > $out/pmc_$name.fetch.json 2> $out/pmc_$name.fetch.err
+  run timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_$name -o write -- python3 $root/bench.py "$@" --no-cpu-baseline --no-extras > $out/pmc_$name.write.json 2> $out/pmc_$name.write.err
 done
 ls -R $out | head -60
