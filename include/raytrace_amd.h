@@ -192,6 +192,31 @@ RT_API int rt_scene_upload(rt_ctx* ctx, const void* spheres_std140, int n_sphere
                            const void* materials_std140, int n_materials, int accel);
 
 /*
+ * Scenes with a second kind of object.  The reference's hittable is a
+ * polymorphic base whose records carry their own byte size (hittable.h:9-14,
+ * hittable_list.h:13-18: offset += h.size), and sphere is its only subclass;
+ * this entry point takes such a list of records of mixed size.  Each record
+ * holds its kind as an int at byte 8 (a word sphere::add leaves untouched,
+ * sphere.h:22-35, so sphere records written into a zeroed buffer are kind 0):
+ *   RT_OBJECT_SPHERE  32 bytes, as in rt_scene_upload
+ *   RT_OBJECT_QUAD    64 bytes: int mat @0, int kind @8, vec3 Q @16 (a corner),
+ *                     vec3 u @32, vec3 v @48 (the two edges from Q)
+ * `objects` holds n_objects records back to back in n_bytes bytes.  A quad is
+ * the parallelogram Q + a u + b v, 0 <= a, b <= 1, hit from either side; its
+ * normal faces the ray, as a sphere's does.  The intersection arithmetic, in
+ * binary32 with one IEEE operation per step, is stated where hit_quad is
+ * defined (csrc/rt_device.cuh) and restated by the oracle.  Objects are
+ * numbered in upload order, spheres and quads alike; of two hits at the same
+ * distance the lower number wins, as in the scan over spheres.
+ * A scene with quads is searched by the scan or by the hierarchy read from
+ * device memory, whose leaves then carry either kind.
+ */
+enum { RT_OBJECT_SPHERE = 0, RT_OBJECT_QUAD = 1 };
+#define RT_QUAD_RECORD_BYTES 64
+RT_API int rt_scene_upload_objects(rt_ctx* ctx, const void* objects, size_t n_bytes, int n_objects,
+                                   const void* materials_std140, int n_materials, int accel);
+
+/*
  * Replaces: the draw that runs the fragment shader over the viewport,
  * glDrawElements at raytrace.cpp:536 (and the never-called tiled variant
  * shader_chunk_pass, raytrace.cpp:598-630, whose c_min/c_max this call's tile

@@ -45,19 +45,25 @@ enum {
   RT_SCENE_DEFAULT = 0,        /* the live scene, raytrace.cpp:396-448: 6 spheres, 7 materials     */
   RT_SCENE_RANDOM_SPHERES = 1, /* the commented-out scene, raytrace.cpp:455-504: 487 spheres       */
   RT_SCENE_PERLIN = 2,         /* ground + one sphere, perlin-modulated lambertian, scale 4         */
-  RT_SCENE_CLOUD = 3           /* n spheres uniform in [-500,500)^3, radius [0.1,1), one material   */
+  RT_SCENE_CLOUD = 3,          /* n spheres uniform in [-500,500)^3, radius [0.1,1), one material   */
+  RT_SCENE_QUAD_ROOM = 4,      /* six quads and three spheres, seven materials (mixed record sizes)  */
+  RT_SCENE_QUAD_CLOUD = 5      /* n objects uniform in [-50,50)^3, every third a quad, four materials */
 };
 
 /*
  * Builds a scene with the scene API into the capture buffers
  * RT_HOST_MATERIAL_BUFFER / RT_HOST_SPHERE_BUFFER of the calling thread
  * (rt_gl_reset first; each buffer is allocated with rt_gl_buffer_data as at
- * raytrace.cpp:384,419).  n and seed are used by RT_SCENE_CLOUD only.
- * Returns the number of spheres (hittable_list::num), or a negative
+ * raytrace.cpp:384,419).  n and seed are used by the two cloud scenes only.
+ * Returns the number of objects (hittable_list::num), or a negative
  * rt_status; *n_materials (nullable) receives material_list::num.
  * Read the bytes with rt_gl_buffer_bytes.
  */
 RT_API int rt_host_build_scene(int scene, int n, uint32_t seed, int* n_materials);
+
+/* Bytes the objects of the calling thread's last rt_host_build_scene take (hittable_list::offset,
+ * hittable_list.h:13-18): 32 per sphere, 64 per quad.  Scenes with quads go to rt_scene_upload_objects. */
+RT_API int rt_host_scene_object_bytes(void);
 
 /* Default camera of each scene (rt_host_build_scene's ids). */
 RT_API int rt_host_scene_camera(int scene, rt_camera* out);

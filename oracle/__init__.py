@@ -32,6 +32,15 @@ def lib():
         L.orc_trace_batch.restype = ctypes.c_int
         L.orc_trace_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, P(RtCounters), ctypes.c_int]
+        L.orc_render_objects.restype = ctypes.c_int
+        L.orc_render_objects.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, P(RtParams),
+                                         ctypes.c_void_p, P(RtCounters), ctypes.c_int]
+        L.orc_trace_batch_objects.restype = ctypes.c_int
+        L.orc_trace_batch_objects.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                              ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, P(RtCounters),
+                                              ctypes.c_int]
+        L.orc_hit_quad.restype = ctypes.c_float
+        L.orc_hit_quad.argtypes = [ctypes.c_char_p, P(ctypes.c_float), P(ctypes.c_float)]
         L.orc_xorshift32.restype = ctypes.c_uint32
         L.orc_xorshift32.argtypes = [P(ctypes.c_uint32)]
         L.orc_rand_float.restype = ctypes.c_float
@@ -78,8 +87,12 @@ def render(scene, params, threads=1, seed_tex=None):
         p.seed_tex = seed_tex.ctypes.data
     accum = np.zeros((p.height, p.width, 3), dtype=np.float32)
     c = RtCounters()
-    rc = lib().orc_render(scene.spheres, scene.n_spheres, scene.materials, scene.n_materials, ctypes.byref(p),
-                          accum.ctypes.data, ctypes.byref(c), int(threads))
+    if hasattr(scene, "objects"):
+        rc = lib().orc_render_objects(scene.objects, len(scene.objects), scene.n_objects, scene.materials, scene.n_materials,
+                                      ctypes.byref(p), accum.ctypes.data, ctypes.byref(c), int(threads))
+    else:
+        rc = lib().orc_render(scene.spheres, scene.n_spheres, scene.materials, scene.n_materials, ctypes.byref(p),
+                              accum.ctypes.data, ctypes.byref(c), int(threads))
     if rc:
         raise RuntimeError(f"orc_render failed ({rc})")
     return accum, c.as_dict()
@@ -102,8 +115,12 @@ def trace(scene, origins, directions, threads=1):
     t = np.empty(n, dtype=np.float32)
     nrm = np.empty((n, 3), dtype=np.float32)
     c = RtCounters()
-    rc = lib().orc_trace_batch(scene.spheres, scene.n_spheres, o.ctypes.data, d.ctypes.data, n, ids.ctypes.data,
-                               t.ctypes.data, nrm.ctypes.data, ctypes.byref(c), int(threads))
+    if hasattr(scene, "objects"):
+        rc = lib().orc_trace_batch_objects(scene.objects, len(scene.objects), scene.n_objects, o.ctypes.data, d.ctypes.data, n,
+                                           ids.ctypes.data, t.ctypes.data, nrm.ctypes.data, ctypes.byref(c), int(threads))
+    else:
+        rc = lib().orc_trace_batch(scene.spheres, scene.n_spheres, o.ctypes.data, d.ctypes.data, n, ids.ctypes.data,
+                                   t.ctypes.data, nrm.ctypes.data, ctypes.byref(c), int(threads))
     if rc:
         raise RuntimeError(f"orc_trace_batch failed ({rc})")
     return ids, t, nrm, c.as_dict()
@@ -111,6 +128,12 @@ def trace(scene, origins, directions, threads=1):
 
 def hit_sphere(centre, radius, direction, origin):
     return float(lib().orc_hit_sphere(_vec(centre), float(radius), _vec(direction), _vec(origin)))
+
+
+def hit_quad(record, direction, origin):
+    """hit_quad on one 64-byte quad record."""
+    assert len(record) == 64
+    return float(lib().orc_hit_quad(record, _vec(direction), _vec(origin)))
 
 
 def shade_sky(direction, albedo):

@@ -102,8 +102,20 @@ Material decode_material(const uint8_t* p) {
   return m;
 }
 
+// A parallelogram (no counterpart in the reference, whose hittable has one subclass, hittable.h:6-15, sphere.h:11):
+// the record rt_scene_upload_objects documents, and what is derived from it once per scene.
+struct Quad {
+  int32_t mat;
+  V3 Q, u, v;
+  V3 normal, w;  // unit normal; n / dot(n, n), n = cross(u, v)
+  float D;       // dot(normal, Q)
+};
+
 struct Scene {
-  std::vector<Sphere> spheres;
+  std::vector<Sphere> spheres;  // one per object; a quad's entry holds its material only
+  std::vector<int32_t> quad_of; // object -> index into quads, or -1 (empty: no quads)
+  std::vector<Quad> quads;      // in upload order
+  std::vector<int32_t> quad_object;
   std::vector<Material> materials;
 };
 
@@ -228,6 +240,39 @@ float hit_sphere(V3 origin, float radius, V3 ray_dir, V3 ray_orig, Counters& k) 
   return -1.0f;  // fs:161
 }
 
+inline V3 cross(V3 a, V3 b) {  // vec3.h:139-144
+  return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+Quad decode_quad(const uint8_t* p) {
+  Quad q;
+  std::memcpy(&q.mat, p + 0, 4);
+  std::memcpy(&q.Q, p + 16, 12);
+  std::memcpy(&q.u, p + 32, 12);
+  std::memcpy(&q.v, p + 48, 12);
+  const V3 n = cross(q.u, q.v);
+  const float nn = dot(n, n);
+  q.normal = (1.0f / std::sqrt(nn)) * n;
+  q.D = dot(q.normal, q.Q);
+  q.w = (1.0f / nn) * n;
+  return q;
+}
+
+// Ray parameter of the hit, or -1.  The plane is met at t = (D - normal.o) / (normal.d) unless the ray runs along
+// it; t must pass the shader's 0.001 gate (fs:153); the point computed at t, relative to Q, has planar coordinates
+// alpha = w.(p x v), beta = w.(u x p), and both must lie in [0, 1].
+float hit_quad(const Quad& q, V3 ray_dir, V3 ray_orig) {
+  const float denom = dot(q.normal, ray_dir);
+  if (std::fabs(denom) < 1e-8f) return -1.0f;
+  const float t = (q.D - dot(q.normal, ray_orig)) / denom;
+  if (!(t > 0.001f)) return -1.0f;
+  const V3 hp = (ray_orig + ray_dir * t) - q.Q;
+  const float alpha = dot(q.w, cross(hp, q.v));
+  const float beta = dot(q.w, cross(q.u, hp));
+  if (!(alpha >= 0.0f && alpha <= 1.0f && beta >= 0.0f && beta <= 1.0f)) return -1.0f;
+  return t;
+}
+
 struct Hit {  // fs:32-39 plus the index and t, which the batch interface reports
   V3 point, normal;
   bool hit, interior;
@@ -248,12 +293,22 @@ Hit hit_any(const Scene& sc, V3 ray_orig, V3 ray_dir, Counters& k) {  // fs:165-
   int si = -1;
   k.c.segments++;
   const int n = (int)sc.spheres.size();
+  const bool mixed = !sc.quad_of.empty();
   for (int i = 0; i < n; i++) {  // fs:176
     const Sphere& sp = sc.spheres[i];
-    float new_t = hit_sphere(sp.origin, sp.radius, ray_dir, ray_orig, k);  // fs:178
+    float new_t = mixed && sc.quad_of[i] >= 0 ? -1.0f : hit_sphere(sp.origin, sp.radius, ray_dir, ray_orig, k);  // fs:178
     if (t < 0.0f || (new_t < t && new_t > 0.001f)) {                       // fs:180
       t = new_t;
       si = i;
+    }
+  }
+  // Quads come after the spheres: one replaces the result when it is nearer, or as near and uploaded earlier.
+  for (size_t qi = 0; qi < sc.quads.size(); qi++) {
+    const float new_t = hit_quad(sc.quads[qi], ray_dir, ray_orig);
+    const int idx = sc.quad_object[qi];
+    if (new_t > 0.001f && (!(t > 0.001f) || new_t < t || (new_t == t && idx < si))) {
+      t = new_t;
+      si = idx;
     }
   }
   h.t = -1.0f;
@@ -261,6 +316,7 @@ Hit hit_any(const Scene& sc, V3 ray_orig, V3 ray_dir, Counters& k) {  // fs:165-
     const Sphere& s = sc.spheres[si];
     h.point = ray_orig + ray_dir * t;                 // fs:188
     h.normal = (h.point - s.origin) / s.radius;       // fs:189
+    if (mixed && sc.quad_of[si] >= 0) h.normal = sc.quads[sc.quad_of[si]].normal;
     if (dot(h.normal, ray_dir) >= 0.0f) {             // fs:190
       h.normal = -h.normal;
       h.interior = true;
@@ -486,9 +542,60 @@ Scene make_scene(const void* spheres, int ns, const void* mats, int nm) {
   return sc;
 }
 
+// Records with their kind at byte 8 (0: sphere, 32 bytes; 1: quad, 64 bytes), n_bytes in all.  False if malformed.
+bool make_scene_objects(Scene& sc, const void* objects, size_t n_bytes, int n, const void* mats, int nm) {
+  sc.spheres.resize(n);
+  sc.quad_of.assign(n, -1);
+  sc.materials.resize(nm);
+  const uint8_t* p = (const uint8_t*)objects;
+  size_t off = 0;
+  for (int i = 0; i < n; i++) {
+    if (off + 32 > n_bytes) return false;
+    int32_t kind;
+    std::memcpy(&kind, p + off + 8, 4);
+    if (kind == 1) {
+      if (off + 64 > n_bytes) return false;
+      const Quad q = decode_quad(p + off);
+      sc.spheres[i] = Sphere{q.mat, 0.0f, v3(0, 0, 0)};
+      sc.quad_of[i] = (int32_t)sc.quads.size();
+      sc.quads.push_back(q);
+      sc.quad_object.push_back(i);
+      off += 64;
+    } else if (kind == 0) {
+      sc.spheres[i] = decode_sphere(p + off);
+      off += 32;
+    } else {
+      return false;
+    }
+  }
+  for (int i = 0; i < nm; i++) sc.materials[i] = decode_material((const uint8_t*)mats + 32 * (size_t)i);
+  return true;
+}
+
+int render_scene(const Scene& sc, int n_materials, const rt_params* p, float* accum, rt_counters* counters, int threads);
+int trace_scene(const Scene& sc, const float* o_xyz, const float* d_xyz, size_t n, int32_t* id, float* t, float* nrm,
+                rt_counters* counters, int threads);
+
 }  // namespace
 
 extern "C" {
+
+// The two entry points below on a list of spheres and quads (the records of rt_scene_upload_objects).
+int orc_render_objects(const void* objects, size_t n_bytes, int n_objects, const void* materials_std140, int n_materials,
+                       const rt_params* p, float* accum, rt_counters* counters, int threads) {
+  if (!p || !accum || n_objects < 0 || n_materials < 0) return -1;
+  Scene sc;
+  if (!make_scene_objects(sc, objects, n_bytes, n_objects, materials_std140, n_materials)) return -1;
+  return render_scene(sc, n_materials, p, accum, counters, threads);
+}
+
+int orc_trace_batch_objects(const void* objects, size_t n_bytes, int n_objects, const float* o_xyz, const float* d_xyz,
+                            size_t n, int32_t* id, float* t, float* nrm, rt_counters* counters, int threads) {
+  static const uint8_t no_materials[32] = {0};
+  Scene sc;
+  if (!make_scene_objects(sc, objects, n_bytes, n_objects, no_materials, 0)) return -1;
+  return trace_scene(sc, o_xyz, d_xyz, n, id, t, nrm, counters, threads);
+}
 
 // Sum of radiance over samples [sample_begin, sample_end) for the pixels of the
 // tile, added sample by sample onto accum (width*height*3 floats, row 0 on top).  `threads` rows
@@ -498,6 +605,14 @@ int orc_render(const void* spheres_std140, int n_spheres, const void* materials_
                int threads) {
   if (!p || !accum || n_spheres < 0 || n_materials < 0) return -1;
   Scene sc = make_scene(spheres_std140, n_spheres, materials_std140, n_materials);
+  return render_scene(sc, n_materials, p, accum, counters, threads);
+}
+
+}  // extern "C"
+
+namespace {
+
+int render_scene(const Scene& sc, int n_materials, const rt_params* p, float* accum, rt_counters* counters, int threads) {
   for (const Sphere& s : sc.spheres)
     if (s.mat < 0 || s.mat >= n_materials) return -1;
   if (threads < 1) threads = 1;
@@ -529,6 +644,10 @@ int orc_render(const void* spheres_std140, int n_spheres, const void* materials_
   return 0;
 }
 
+}  // namespace
+
+extern "C" {
+
 // End of main(), fs:135-140, and the RGB8 store (raytrace.cpp:574): mean,
 // gamma 1/2.2, clamp to [0,1], round to nearest.
 void orc_resolve(const float* accum, size_t n_pixels, int samples, float* rgb_linear, uint8_t* rgb8) {
@@ -550,6 +669,15 @@ int orc_trace_batch(const void* spheres_std140, int n_spheres, const float* o_xy
                     rt_counters* counters, int threads) {
   static const uint8_t no_materials[32] = {0};
   Scene sc = make_scene(spheres_std140, n_spheres, no_materials, 0);
+  return trace_scene(sc, o_xyz, d_xyz, n, id, t, nrm, counters, threads);
+}
+
+}  // extern "C"
+
+namespace {
+
+int trace_scene(const Scene& sc, const float* o_xyz, const float* d_xyz, size_t n, int32_t* id, float* t, float* nrm,
+                rt_counters* counters, int threads) {
   if (threads < 1) threads = 1;
   std::vector<Counters> ks((size_t)threads);
   auto work = [&](int tid) {
@@ -576,7 +704,15 @@ int orc_trace_batch(const void* spheres_std140, int n_spheres, const float* o_xy
   return 0;
 }
 
+}  // namespace
+
+extern "C" {
+
 // ---- scalar entry points for the known-answer tests ------------------------
+
+float orc_hit_quad(const void* record64, const float* d, const float* o) {
+  return hit_quad(decode_quad((const uint8_t*)record64), v3(d[0], d[1], d[2]), v3(o[0], o[1], o[2]));
+}
 
 uint32_t orc_xorshift32(uint32_t* state) {
   Rng s{*state, RT_RNG_XORSHIFT_REF};

@@ -7,6 +7,7 @@ in HIP kernels (raytrace_amd/csrc).
 """
 import ctypes
 import os
+import struct
 
 import numpy as np
 
@@ -15,7 +16,7 @@ from ._lib import RtCamera, RtCounters, RtParams  # noqa: F401
 
 ACCEL_LINEAR, ACCEL_LBVH = 0, 1
 RNG_XORSHIFT_REF, RNG_COUNTER = 0, 1
-SCENE_DEFAULT, SCENE_RANDOM_SPHERES, SCENE_PERLIN, SCENE_CLOUD = 0, 1, 2, 3
+SCENE_DEFAULT, SCENE_RANDOM_SPHERES, SCENE_PERLIN, SCENE_CLOUD, SCENE_QUAD_ROOM, SCENE_QUAD_CLOUD = 0, 1, 2, 3, 4, 5
 MATERIAL_BUFFER, SPHERE_BUFFER = 1, 2
 MAT_NOTHING, MAT_LAMBERTIAN, MAT_METALLIC, MAT_DIALECTRIC, MAT_PERLIN_LAMBERTIAN = 0, 1, 2, 3, 4
 RECORD_BYTES = 32
@@ -44,6 +45,40 @@ class Scene:
         return len(self.materials) // RECORD_BYTES
 
 
+OBJECT_SPHERE, OBJECT_QUAD = 0, 1
+QUAD_RECORD_BYTES = 64
+
+
+def sphere_record(mat, radius, origin) -> bytes:
+    """One 32-byte sphere record (mat @0, radius @4, kind 0 @8, origin @16)."""
+    return struct.pack("<ifi4x3f4x", int(mat), float(radius), OBJECT_SPHERE, *[float(x) for x in origin])
+
+
+def quad_record(mat, corner, edge_u, edge_v) -> bytes:
+    """One 64-byte quad record (mat @0, kind 1 @8, Q @16, u @32, v @48)."""
+    f = [float(x) for x in (*corner, *edge_u, *edge_v)]
+    return struct.pack("<i4xi4x3f4x3f4x3f4x", int(mat), OBJECT_QUAD, *f)
+
+
+def material_record(ident, kind, albedo=(0.0, 0.0, 0.0), param1=0.0) -> bytes:
+    """One 32-byte material record (id @0, type @4, param1 @8, albedo @16)."""
+    return struct.pack("<iif4x3f4x", int(ident), int(kind), float(param1), *[float(x) for x in albedo])
+
+
+class ObjectScene(Scene):
+    """A list of spheres and quads: records of rt_scene_upload_objects, back to back, kinds at byte 8."""
+
+    def __init__(self, objects: bytes, n_objects: int, materials: bytes):
+        assert len(materials) % RECORD_BYTES == 0
+        self.objects = objects
+        self.n_objects = int(n_objects)
+        self.materials = materials
+
+    @property
+    def n_spheres(self):  # objects of either kind: what ids and counts refer to
+        return self.n_objects
+
+
 def build_scene(scene_id, n=0, seed=0) -> Scene:
     """Run a scene builder of the host harness (through the scene description API) and collect the captured bytes."""
     lib = _lib.host_lib()
@@ -60,7 +95,15 @@ def build_scene(scene_id, n=0, seed=0) -> Scene:
             raise RtError(-3, f"captured buffer {buffer_id} holds {size.value} bytes, need {need}")
         return ctypes.string_at(ptr, need)
 
-    scene = Scene(grab(SPHERE_BUFFER, ns), grab(MATERIAL_BUFFER, nm.value))
+    if scene_id in (SCENE_QUAD_ROOM, SCENE_QUAD_CLOUD):
+        nbytes = lib.rt_host_scene_object_bytes()
+        size = ctypes.c_size_t(0)
+        ptr = lib.rt_gl_buffer_bytes(SPHERE_BUFFER, ctypes.byref(size))
+        if ptr is None or size.value < nbytes:
+            raise RtError(-3, f"captured object buffer holds {size.value} bytes, need {nbytes}")
+        scene = ObjectScene(ctypes.string_at(ptr, nbytes), ns, grab(MATERIAL_BUFFER, nm.value))
+    else:
+        scene = Scene(grab(SPHERE_BUFFER, ns), grab(MATERIAL_BUFFER, nm.value))
     lib.rt_gl_reset()
     return scene
 
@@ -146,6 +189,10 @@ class Renderer:
             pass
 
     def upload(self, scene: Scene, accel=ACCEL_LINEAR):
+        if isinstance(scene, ObjectScene):
+            self._check(self.lib.rt_scene_upload_objects(self.ctx, scene.objects, len(scene.objects), scene.n_objects,
+                                                         scene.materials, scene.n_materials, int(accel)))
+            return
         self._check(self.lib.rt_scene_upload(self.ctx, scene.spheres, scene.n_spheres, scene.materials,
                                              scene.n_materials, int(accel)))
 

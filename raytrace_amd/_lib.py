@@ -76,13 +76,13 @@ class RtCamera(ctypes.Structure):
 # Entry points every build of the device library must export (checked by tests).
 DEVICE_SYMBOLS = [
     "rt_last_error", "rt_init", "rt_destroy", "rt_gl_bind_buffer", "rt_gl_buffer_sub_data", "rt_gl_buffer_data",
-    "rt_gl_buffer_bytes", "rt_gl_reset", "rt_gl_dropped_writes", "rt_scene_upload", "rt_render", "rt_render_counted",
+    "rt_gl_buffer_bytes", "rt_gl_reset", "rt_gl_dropped_writes", "rt_scene_upload", "rt_scene_upload_objects", "rt_render", "rt_render_counted",
     "rt_clear", "rt_set_accumulator", "rt_set_accumulated_samples", "rt_readback", "rt_trace_batch",
     "rt_trace_batch_device", "rt_synchronize", "rt_get_counters", "rt_last_kernel_ms", "rt_last_build_ms",
     "rt_lbvh_depth", "rt_device_count", "rt_seed_texture", "rt_accumulator_read", "rt_accumulator_write",
     "rt_render_chunk", "rt_trace_batch_noalloc", "rt_eval_perlin", "rt_eval_perlin_gradient", "rt_set_scratch_budget", "rt_get_scene_info", "rt_get_stream",
 ]
-HOST_SYMBOLS = ["rt_host_camera", "rt_host_build_scene", "rt_host_scene_camera", "rt_host_gen_rays",
+HOST_SYMBOLS = ["rt_host_camera", "rt_host_build_scene", "rt_host_scene_object_bytes", "rt_host_scene_camera", "rt_host_gen_rays",
                 "rt_host_blit_nearest", "rt_host_height_for_width", "rt_host_write_ppm",
                 "rt_gl_bind_buffer", "rt_gl_buffer_sub_data", "rt_gl_buffer_data", "rt_gl_buffer_bytes", "rt_gl_reset"]
 
@@ -113,6 +113,8 @@ def host_lib():
         _declare_capture(lib)
         lib.rt_host_camera.restype = ctypes.c_int
         lib.rt_host_camera.argtypes = [ctypes.POINTER(RtCamera), ctypes.c_int, ctypes.c_int, ctypes.POINTER(RtParams)]
+        lib.rt_host_scene_object_bytes.restype = ctypes.c_int
+        lib.rt_host_scene_object_bytes.argtypes = []
         lib.rt_host_build_scene.restype = ctypes.c_int
         lib.rt_host_build_scene.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int)]
         lib.rt_host_scene_camera.restype = ctypes.c_int
@@ -153,6 +155,9 @@ def device_lib():
         lib.rt_init.argtypes = [ctypes.c_int, P(ctypes.c_void_p)]
         lib.rt_destroy.restype = None
         lib.rt_destroy.argtypes = [ctypes.c_void_p]
+        lib.rt_scene_upload_objects.restype = ctypes.c_int
+        lib.rt_scene_upload_objects.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
+                                                ctypes.c_int, ctypes.c_int]
         lib.rt_scene_upload.restype = ctypes.c_int
         lib.rt_scene_upload.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         for name in ("rt_render", "rt_render_counted"):

@@ -143,6 +143,9 @@ struct rt_ctx {
   dev_buf<float> inv_r;
   dev_buf<int32_t> sph_mat, mat_type;
   dev_buf<float4> mat_a;
+  int n_quads = 0;
+  dev_buf<float4> quad_qd, quad_u, quad_v, quad_n, quad_w;
+  dev_buf<int32_t> quad_idx, quad_of;
   dev_buf<float2> perlin_grad;  // gradient table of the noise texture, built with the first scene that uses it
   bool have_noise = false;
   // hierarchy
@@ -204,6 +207,14 @@ struct rt_ctx {
     s.mat_type = mat_type.p;
     s.noise.grad = have_noise ? perlin_grad.p : nullptr;
     s.noise.half = kPerlinHalf;
+    s.n_quads = n_quads;
+    s.quad_qd = quad_qd.p;
+    s.quad_u = quad_u.p;
+    s.quad_v = quad_v.p;
+    s.quad_n = quad_n.p;
+    s.quad_w = quad_w.p;
+    s.quad_idx = quad_idx.p;
+    s.quad_of = quad_of.p;
     s.n_big = n_big;
     s.big_sph = big_sph.p;
     s.big_idx = big_idx.p;
@@ -587,6 +598,8 @@ scene_counts counts_of(const rt_ctx* c) {
 
 int choose_search(const rt_ctx* c) {
   const scene_counts n = counts_of(c);
+  if (c->n_quads > 0)  // scenes with quads: the scan from HBM, or the tree read from HBM with leaf steps
+    return c->accel == RT_ACCEL_LBVH && c->n_spheres >= 1 ? SEARCH_TREE_GLB_NODE_Q : SEARCH_LINEAR_Q;
   if (c->accel != RT_ACCEL_LBVH || c->n_spheres < 1)
     return search_scene_lds_bytes<SEARCH_LINEAR_LDS>(n) <= kLdsTreeBudget && c->n_spheres >= 1 ? SEARCH_LINEAR_LDS
                                                                                                : SEARCH_LINEAR;
@@ -611,6 +624,8 @@ const char* stored_name(int search) {
     case SEARCH_TREE_LDS_RAY: return "rt_render_stored_kernel<lbvh4,lds,pad_ray>";
     case SEARCH_TREE_LDS_NODE: return "rt_render_stored_kernel<lbvh4,lds,pad_node>";
     case SEARCH_TREE_GLB_RAY: return "rt_render_stored_kernel<lbvh4,hbm,pad_ray>";
+    case SEARCH_LINEAR_Q: return "rt_render_stored_kernel<linear,quads>";
+    case SEARCH_TREE_GLB_NODE_Q: return "rt_render_stored_kernel<lbvh4,hbm,pad_node,quads>";
     default: return "rt_render_stored_kernel<lbvh4,hbm,pad_node>";
   }
 }
@@ -622,6 +637,8 @@ const char* search_name(int search, bool render) {
     case SEARCH_TREE_LDS_RAY: return render ? "rt_render_kernel<lbvh4,lds,pad_ray>" : "rt_trace_kernel<lbvh4,lds,pad_ray>";
     case SEARCH_TREE_LDS_NODE: return render ? "rt_render_kernel<lbvh4,lds,pad_node>" : "rt_trace_kernel<lbvh4,lds,pad_node>";
     case SEARCH_TREE_GLB_RAY: return render ? "rt_render_kernel<lbvh4,hbm,pad_ray>" : "rt_trace_kernel<lbvh4,hbm,pad_ray>";
+    case SEARCH_LINEAR_Q: return render ? "rt_render_kernel<linear,quads>" : "rt_trace_kernel<linear,quads>";
+    case SEARCH_TREE_GLB_NODE_Q: return render ? "rt_render_kernel<lbvh4,hbm,pad_node,quads>" : "rt_trace_kernel<lbvh4,hbm,pad_node,quads>";
     default: return render ? "rt_render_kernel<lbvh4,hbm,pad_node>" : "rt_trace_kernel<lbvh4,hbm,pad_node>";
   }
 }
@@ -920,6 +937,7 @@ bool stored_fits(const rt_ctx* c) {
     case SEARCH_TREE_LDS_NODE: return stored_lds_bytes<SEARCH_TREE_LDS_NODE>(c) <= kMaxLdsBytes;
     case SEARCH_TREE_GLB_RAY: return stored_lds_bytes<SEARCH_TREE_GLB_RAY>(c) <= kMaxLdsBytes;
     case SEARCH_TREE_GLB_NODE: return stored_lds_bytes<SEARCH_TREE_GLB_NODE>(c) <= kMaxLdsBytes;
+    case SEARCH_TREE_GLB_NODE_Q: return stored_lds_bytes<SEARCH_TREE_GLB_NODE_Q>(c) <= kMaxLdsBytes;
     case SEARCH_LINEAR_LDS: return stored_lds_bytes<SEARCH_LINEAR_LDS>(c) <= kMaxLdsBytes;
     default: return true;
   }
@@ -1038,6 +1056,8 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       case SEARCH_TREE_LDS_NODE: return launch_render<SEARCH_TREE_LDS_NODE>(c, rp, counted, c->stream, ra);
       case SEARCH_TREE_GLB_RAY: return launch_render<SEARCH_TREE_GLB_RAY>(c, rp, counted, c->stream, ra);
       case SEARCH_TREE_GLB_NODE: return launch_render<SEARCH_TREE_GLB_NODE>(c, rp, counted, c->stream, ra);
+      case SEARCH_TREE_GLB_NODE_Q: return launch_render<SEARCH_TREE_GLB_NODE_Q>(c, rp, counted, c->stream, ra);
+      case SEARCH_LINEAR_Q: return launch_render<SEARCH_LINEAR_Q>(c, rp, counted, c->stream, ra);
       case SEARCH_LINEAR_LDS: return launch_render<SEARCH_LINEAR_LDS>(c, rp, counted, c->stream, ra);
       default: return launch_render<SEARCH_LINEAR>(c, rp, counted, c->stream, ra);
     }
@@ -1051,6 +1071,8 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       case SEARCH_TREE_LDS_NODE: return launch_stored<SEARCH_TREE_LDS_NODE>(c, counted, c->stream, ra);
       case SEARCH_TREE_GLB_RAY: return launch_stored<SEARCH_TREE_GLB_RAY>(c, counted, c->stream, ra);
       case SEARCH_TREE_GLB_NODE: return launch_stored<SEARCH_TREE_GLB_NODE>(c, counted, c->stream, ra);
+      case SEARCH_TREE_GLB_NODE_Q: return launch_stored<SEARCH_TREE_GLB_NODE_Q>(c, counted, c->stream, ra);
+      case SEARCH_LINEAR_Q: return launch_stored<SEARCH_LINEAR_Q>(c, counted, c->stream, ra);
       case SEARCH_LINEAR_LDS: return launch_stored<SEARCH_LINEAR_LDS>(c, counted, c->stream, ra);
       default: return launch_stored<SEARCH_LINEAR>(c, counted, c->stream, ra);
     }
@@ -1281,6 +1303,7 @@ void rt_destroy(rt_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   c->sph.release(); c->inv_r.release(); c->sph_mat.release(); c->mat_type.release(); c->mat_a.release();
+  c->quad_qd.release(); c->quad_u.release(); c->quad_v.release(); c->quad_n.release(); c->quad_w.release(); c->quad_idx.release(); c->quad_of.release();
   c->big_sph.release(); c->big_idx.release(); c->tree_sph.release(); c->tree_r.release(); c->tree_orig.release();
   c->nodes.release(); c->qnodes.release(); c->leaf_sph.release(); c->leaf_r.release(); c->leaf_idx.release();
   c->accum_own.release(); c->seed_tex.release(); c->queue.release(); c->counters.release(); c->ovf.release(); c->build.release(); c->perlin_grad.release();
@@ -1304,8 +1327,14 @@ void rt_destroy(rt_ctx* c) {
   delete c;
 }
 
-int rt_scene_upload(rt_ctx* c, const void* spheres_std140, int n_spheres, const void* materials_std140, int n_materials,
-                    int accel) {
+}  // extern "C"
+
+namespace {
+
+// rt_scene_upload and rt_scene_upload_objects.  `tagged`: the records carry their kind at byte 8 and are 32 (sphere)
+// or 64 (quad) bytes long, `n_bytes` in all; otherwise n_spheres 32-byte sphere slots whose bytes 8..15 mean nothing.
+int upload_impl(rt_ctx* c, const void* spheres_std140, size_t n_bytes, int n_spheres, bool tagged, const void* materials_std140,
+                int n_materials, int accel) {
   int rc = check_ctx(c);
   if (rc) return rc;
   if (n_spheres < 0 || n_materials < 0 || (n_spheres > 0 && !spheres_std140) || (n_materials > 0 && !materials_std140))
@@ -1317,22 +1346,58 @@ int rt_scene_upload(rt_ctx* c, const void* spheres_std140, int n_spheres, const 
   const size_t ns = (size_t)n_spheres, nm = (size_t)n_materials;
   std::vector<float4> sph(ns);
   std::vector<float> radius(ns), inv_r(ns);
-  std::vector<int32_t> sph_mat(ns), mat_type(nm);
-  std::vector<float4> mat_a(nm);
+  std::vector<int32_t> sph_mat(ns), mat_type(nm), quad_of(ns, -1), quad_idx;
+  std::vector<float4> mat_a(nm), quad_qd, quad_u, quad_v, quad_n, quad_w;
+  std::vector<char> is_quad(ns, 0);
   const uint8_t* sp = static_cast<const uint8_t*>(spheres_std140);
+  size_t off = 0;
   for (size_t i = 0; i < ns; i++) {
-    const uint8_t* r = sp + RT_RECORD_BYTES * i;
+    int32_t kind = RT_OBJECT_SPHERE;
+    if (tagged) {
+      if (off + RT_RECORD_BYTES > n_bytes) return fail(RT_ERR_INVALID, "object %zu begins beyond the %zu bytes given", i, n_bytes);
+      std::memcpy(&kind, sp + off + 8, 4);
+      if (kind != RT_OBJECT_SPHERE && kind != RT_OBJECT_QUAD) return fail(RT_ERR_INVALID, "object %zu has unknown kind %d", i, kind);
+      if (kind == RT_OBJECT_QUAD && off + RT_QUAD_RECORD_BYTES > n_bytes) return fail(RT_ERR_INVALID, "quad %zu ends beyond the %zu bytes given", i, n_bytes);
+    }
+    const uint8_t* r = sp + off;
     int32_t m;
-    float rad, o[3];
     std::memcpy(&m, r + 0, 4);
-    std::memcpy(&rad, r + 4, 4);
-    std::memcpy(o, r + 16, 12);
     if (m < 0 || m >= n_materials)
       return fail(RT_ERR_INVALID, "sphere %zu names material %d, but only %d were uploaded", i, m, n_materials);
+    sph_mat[i] = m;
+    if (kind == RT_OBJECT_QUAD) {
+      // corner and edges; the derived quantities in binary32, one IEEE operation each, in the order quad_dev states
+      float Q[3], u[3], v[3];
+      std::memcpy(Q, r + 16, 12);
+      std::memcpy(u, r + 32, 12);
+      std::memcpy(v, r + 48, 12);
+      const float n[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+      const float nn = (n[0] * n[0] + n[1] * n[1]) + n[2] * n[2];
+      const float inv_len = 1.0f / std::sqrt(nn), inv_nn = 1.0f / nn;
+      const float normal[3] = {inv_len * n[0], inv_len * n[1], inv_len * n[2]};
+      const float D = (normal[0] * Q[0] + normal[1] * Q[1]) + normal[2] * Q[2];
+      quad_of[i] = (int32_t)quad_idx.size();
+      quad_idx.push_back((int32_t)i);
+      quad_qd.push_back(make_float4(Q[0], Q[1], Q[2], D));
+      quad_u.push_back(make_float4(u[0], u[1], u[2], 0.0f));
+      quad_v.push_back(make_float4(v[0], v[1], v[2], 0.0f));
+      quad_n.push_back(make_float4(normal[0], normal[1], normal[2], 0.0f));
+      quad_w.push_back(make_float4(inv_nn * n[0], inv_nn * n[1], inv_nn * n[2], 0.0f));
+      // among the spheres: a record no ray hits (r * r = -infinity makes every discriminant negative)
+      is_quad[i] = 1;
+      sph[i] = make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff());
+      radius[i] = 0.0f;
+      inv_r[i] = 0.0f;
+      off += RT_QUAD_RECORD_BYTES;
+      continue;
+    }
+    float rad, o[3];
+    std::memcpy(&rad, r + 4, 4);
+    std::memcpy(o, r + 16, 12);
     sph[i] = make_float4(o[0], o[1], o[2], rad * rad);
     radius[i] = rad;
     inv_r[i] = 1.0f / rad;
-    sph_mat[i] = m;
+    off += RT_RECORD_BYTES;
   }
   const uint8_t* mp = static_cast<const uint8_t*>(materials_std140);
   for (size_t i = 0; i < nm; i++) {
@@ -1350,6 +1415,18 @@ int rt_scene_upload(rt_ctx* c, const void* spheres_std140, int n_spheres, const 
   HIP_TRY(c->sph_mat.upload(sph_mat, c->stream));
   HIP_TRY(c->mat_type.upload(mat_type, c->stream));
   HIP_TRY(c->mat_a.upload(mat_a, c->stream));
+  c->n_quads = (int)quad_idx.size();
+  HIP_TRY(c->quad_qd.upload(quad_qd, c->stream));
+  HIP_TRY(c->quad_u.upload(quad_u, c->stream));
+  HIP_TRY(c->quad_v.upload(quad_v, c->stream));
+  HIP_TRY(c->quad_n.upload(quad_n, c->stream));
+  HIP_TRY(c->quad_w.upload(quad_w, c->stream));
+  HIP_TRY(c->quad_idx.upload(quad_idx, c->stream));
+  if (c->n_quads > 0) {
+    HIP_TRY(c->quad_of.upload(quad_of, c->stream));
+  } else {
+    c->quad_of.release();
+  }
   c->have_noise = false;
   for (size_t i = 0; i < nm; i++) c->have_noise = c->have_noise || mat_type[i] == RT_MAT_PERLIN_LAMBERTIAN;
   if (c->have_noise) {
@@ -1365,14 +1442,19 @@ int rt_scene_upload(rt_ctx* c, const void* spheres_std140, int n_spheres, const 
   c->r_max = c->r_median = c->r_min = 0.0f;
   float r_min = 3.0e38f;
   if (accel == RT_ACCEL_LBVH && ns > 0) {
-    std::vector<float> absr(ns);
-    for (size_t i = 0; i < ns; i++) absr[i] = std::fabs(radius[i]);
-    std::vector<float> sorted = absr;
-    std::nth_element(sorted.begin(), sorted.begin() + ns / 2, sorted.end());
-    const float median = sorted[ns / 2];
-    std::vector<size_t> cand;
+    std::vector<float> absr(ns), sorted;
+    for (size_t i = 0; i < ns; i++) {
+      absr[i] = std::fabs(radius[i]);
+      if (!is_quad[i]) sorted.push_back(absr[i]);
+    }
+    float median = 0.0f;
+    if (!sorted.empty()) {
+      std::nth_element(sorted.begin(), sorted.begin() + sorted.size() / 2, sorted.end());
+      median = sorted[sorted.size() / 2];
+    }
+    std::vector<size_t> cand;  // quads always go into the tree
     for (size_t i = 0; i < ns; i++)
-      if (absr[i] > kBigFactor * median || !(absr[i] < 3.0e37f)) cand.push_back(i);
+      if (!is_quad[i] && (absr[i] > kBigFactor * median || !(absr[i] < 3.0e37f))) cand.push_back(i);
     if ((int)cand.size() > kMaxBig) {  // keep only the largest ones out of the tree
       std::partial_sort(cand.begin(), cand.begin() + kMaxBig, cand.end(), [&](size_t x, size_t y) { return absr[x] > absr[y]; });
       cand.resize(kMaxBig);
@@ -1385,6 +1467,18 @@ int rt_scene_upload(rt_ctx* c, const void* spheres_std140, int n_spheres, const 
       if (is_big[i]) {
         big_sph.push_back(sph[i]);
         big_idx.push_back((int32_t)i);
+      } else if (is_quad[i]) {
+        // leaf box: the cube around the sphere through the four corners, centred between them (radius rounded up);
+        // w = -infinity tells the leaf test to look the quad up
+        const float4 Q = quad_qd[quad_of[i]], u = quad_u[quad_of[i]], v = quad_v[quad_of[i]];
+        const double sx = (double)u.x + v.x, sy = (double)u.y + v.y, sz = (double)u.z + v.z;
+        const double dx = (double)u.x - v.x, dy = (double)u.y - v.y, dz = (double)u.z - v.z;
+        const double half = 0.5 * std::sqrt(std::fmax(sx * sx + sy * sy + sz * sz, dx * dx + dy * dy + dz * dz));
+        const float cx = (float)(Q.x + 0.5 * sx), cy = (float)(Q.y + 0.5 * sy), cz = (float)(Q.z + 0.5 * sz);
+        const float slack = 2.4e-7f * (std::fabs(cx) + std::fabs(cy) + std::fabs(cz));  // the rounding of the centre
+        tree_sph.push_back(make_float4(cx, cy, cz, -__builtin_inff()));
+        tree_r.push_back((float)(half * 1.000001) + slack);
+        tree_orig.push_back((int32_t)i);
       } else {
         tree_sph.push_back(sph[i]);
         tree_r.push_back(radius[i]);
@@ -1417,7 +1511,7 @@ int rt_scene_upload(rt_ctx* c, const void* spheres_std140, int n_spheres, const 
   c->builder = RT_BUILDER_NONE;
   if (accel == RT_ACCEL_LBVH && c->n_leaf > 0) {
     bool built = false;
-    if (host_builder_enabled() && c->n_leaf >= 2 && c->n_leaf <= kSahMaxLeaves) {
+    if (host_builder_enabled() && c->n_quads == 0 && c->n_leaf >= 2 && c->n_leaf <= kSahMaxLeaves) {
       bool finite = true;
       for (size_t i = 0; i < tree_sph.size(); i++)
         finite = finite && std::isfinite(tree_sph[i].x) && std::isfinite(tree_sph[i].y) && std::isfinite(tree_sph[i].z) &&
@@ -1439,7 +1533,8 @@ int rt_scene_upload(rt_ctx* c, const void* spheres_std140, int n_spheres, const 
     }
   }
   c->search = choose_search(c);
-  if ((c->search == SEARCH_TREE_GLB_RAY || c->search == SEARCH_TREE_GLB_NODE) && c->n_nodes > 0) {
+  if ((c->search == SEARCH_TREE_GLB_RAY || c->search == SEARCH_TREE_GLB_NODE || c->search == SEARCH_TREE_GLB_NODE_Q) &&
+      c->n_nodes > 0) {
     HIP_TRY(c->qnodes.resize((size_t)c->n_nodes));
     lbvh_quantize_kernel<<<(unsigned)((c->n_nodes + 255) / 256), 256, 0, c->stream>>>(c->nodes.p, c->n_nodes, c->qnodes.p);
     HIP_TRY(hipGetLastError());
@@ -1447,6 +1542,21 @@ int rt_scene_upload(rt_ctx* c, const void* spheres_std140, int n_spheres, const 
   }
   c->have_scene = true;
   return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_scene_upload(rt_ctx* c, const void* spheres_std140, int n_spheres, const void* materials_std140, int n_materials,
+                    int accel) {
+  return upload_impl(c, spheres_std140, (size_t)(n_spheres > 0 ? n_spheres : 0) * RT_RECORD_BYTES, n_spheres, false,
+                     materials_std140, n_materials, accel);
+}
+
+int rt_scene_upload_objects(rt_ctx* c, const void* objects, size_t n_bytes, int n_objects, const void* materials_std140,
+                            int n_materials, int accel) {
+  return upload_impl(c, objects, n_bytes, n_objects, true, materials_std140, n_materials, accel);
 }
 
 int rt_render(rt_ctx* c, const rt_params* p) { return render_impl(c, p, false); }
@@ -1600,6 +1710,8 @@ int rt_trace_batch_device(rt_ctx* c, const float* o_xyz, const float* d_xyz, siz
     case SEARCH_TREE_LDS_NODE: e = launch_trace<SEARCH_TREE_LDS_NODE>(c, counted != 0, c->stream, a); break;
     case SEARCH_TREE_GLB_RAY: e = launch_trace<SEARCH_TREE_GLB_RAY>(c, counted != 0, c->stream, a); break;
     case SEARCH_TREE_GLB_NODE: e = launch_trace<SEARCH_TREE_GLB_NODE>(c, counted != 0, c->stream, a); break;
+    case SEARCH_TREE_GLB_NODE_Q: e = launch_trace<SEARCH_TREE_GLB_NODE_Q>(c, counted != 0, c->stream, a); break;
+    case SEARCH_LINEAR_Q: e = launch_trace<SEARCH_LINEAR_Q>(c, counted != 0, c->stream, a); break;
     case SEARCH_LINEAR_LDS: e = launch_trace<SEARCH_LINEAR_LDS>(c, counted != 0, c->stream, a); break;
     default: e = launch_trace<SEARCH_LINEAR>(c, counted != 0, c->stream, a); break;
   }
@@ -1647,6 +1759,8 @@ int rt_trace_batch_noalloc(rt_ctx* c, const float* o_xyz, const float* d_xyz, si
     case SEARCH_TREE_LDS_NODE: e = launch_trace<SEARCH_TREE_LDS_NODE>(c, false, c->stream, a, ovf, ovf_bytes); break;
     case SEARCH_TREE_GLB_RAY: e = launch_trace<SEARCH_TREE_GLB_RAY>(c, false, c->stream, a, ovf, ovf_bytes); break;
     case SEARCH_TREE_GLB_NODE: e = launch_trace<SEARCH_TREE_GLB_NODE>(c, false, c->stream, a, ovf, ovf_bytes); break;
+    case SEARCH_TREE_GLB_NODE_Q: e = launch_trace<SEARCH_TREE_GLB_NODE_Q>(c, false, c->stream, a, ovf, ovf_bytes); break;
+    case SEARCH_LINEAR_Q: e = launch_trace<SEARCH_LINEAR_Q>(c, false, c->stream, a, ovf, ovf_bytes); break;
     case SEARCH_LINEAR_LDS: e = launch_trace<SEARCH_LINEAR_LDS>(c, false, c->stream, a, ovf, ovf_bytes); break;
     default: e = launch_trace<SEARCH_LINEAR>(c, false, c->stream, a, ovf, ovf_bytes); break;
   }

@@ -182,6 +182,32 @@ RT_DEV void sphere_disc(float cx, float cy, float cz, float r2, f3 o, f3 d, floa
   disc = h * h - a * c;
 }
 
+// ---- quads: the second kind of object ----------------------------------------
+// No counterpart in the reference, whose hittable base (hittable.h:9-14) anticipates other objects but has only the
+// sphere: a parallelogram Q + a*u + b*v, 0 <= a, b <= 1.  From the corner and the two edge vectors the upload
+// derives, once, in binary32 and in this order: n = cross(u, v), nn = dot(n, n), normal = (1 / sqrt(nn)) * n,
+// D = dot(normal, Q), w = (1 / nn) * n.
+RT_DEV f3 cross3(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }  // as vec3.h:139-144
+
+struct quad_dev {
+  f3 Q, u, v, normal, w;
+  float D;
+};
+
+// The ray parameter at which o + t*d meets the quad, or -1: the plane's parameter must exceed the shader's 0.001
+// (fs:153), and the planar coordinates of the point computed at it lie in [0,1]^2.
+RT_DEV float hit_quad(const quad_dev& q, f3 o, f3 d) {
+  const float denom = dot3(q.normal, d);
+  if (fabsf(denom) < 1e-8f) return -1.0f;
+  const float t = (q.D - dot3(q.normal, o)) / denom;
+  if (!(t > 0.001f)) return -1.0f;
+  const f3 hp = (o + d * t) - q.Q;
+  const float alpha = dot3(q.w, cross3(hp, q.v));
+  const float beta = dot3(q.w, cross3(q.u, hp));
+  if (!(alpha >= 0.0f && alpha <= 1.0f && beta >= 0.0f && beta <= 1.0f)) return -1.0f;
+  return t;
+}
+
 // ---- 2-D gradient noise (perlin.h:11-85) -----------------------------------
 
 RT_DEV void perlin_gradient(int ix, int iy, float& gx, float& gy) {  // perlin.h:31-43

@@ -11,13 +11,16 @@
 //                      scenes): one copy per 1024-thread workgroup, one-word stack entries
 //   SEARCH_TREE_GLB_*  4-wide LBVH read from HBM / caches (large scenes)
 //   *_RAY / *_NODE     the box-growing rule (rt_scene_dev.cuh)
+//   *_Q                the two searches of scenes that hold quads beside spheres: the scan, and the tree read from HBM
 enum {
   SEARCH_LINEAR = 0,
   SEARCH_TREE_LDS_RAY = 1,
   SEARCH_TREE_LDS_NODE = 2,
   SEARCH_TREE_GLB_RAY = 3,
   SEARCH_TREE_GLB_NODE = 4,
-  SEARCH_LINEAR_LDS = 5
+  SEARCH_LINEAR_LDS = 5,
+  SEARCH_LINEAR_Q = 6,
+  SEARCH_TREE_GLB_NODE_Q = 7
 };
 
 #ifndef RT_TRACE_WAVES
@@ -32,7 +35,8 @@ enum {
 
 template <int SEARCH>
 struct search_traits {
-  static constexpr bool tree = SEARCH >= SEARCH_TREE_LDS_RAY && SEARCH <= SEARCH_TREE_GLB_NODE;
+  static constexpr bool quads = SEARCH == SEARCH_LINEAR_Q || SEARCH == SEARCH_TREE_GLB_NODE_Q;
+  static constexpr bool tree = (SEARCH >= SEARCH_TREE_LDS_RAY && SEARCH <= SEARCH_TREE_GLB_NODE) || SEARCH == SEARCH_TREE_GLB_NODE_Q;
   static constexpr bool lds = SEARCH == SEARCH_TREE_LDS_RAY || SEARCH == SEARCH_TREE_LDS_NODE;
   static constexpr bool scan_lds = SEARCH == SEARCH_LINEAR_LDS;
   static constexpr bool pad_ray = SEARCH == SEARCH_TREE_LDS_RAY || SEARCH == SEARCH_TREE_GLB_RAY;
@@ -220,7 +224,7 @@ RT_DEV void search_setup(const scene_dev& sc, scene_view& sv, uint32_t*& stack_c
 template <int SEARCH, bool COUNTED>
 struct searcher {
   using T = search_traits<SEARCH>;
-  tree_search<T::pad_ray, T::lds, T::stack, COUNTED> ts;
+  tree_search<T::pad_ray, T::lds, T::stack, COUNTED, T::quads> ts;
   uint32_t ref_mask;  // wave-uniform (scene_dev::ref_mask), set by the kernel before the first step
   RT_DEV bool begin(const scene_dev& sc, const scene_view& sv, f3 o, f3 d, lane_counters& k) {
     if (T::tree) return ts.begin(sc, sv, o, d, k);
@@ -245,10 +249,11 @@ struct searcher {
     ts.step_node(sv, stk, staged, k);
   }
   RT_DEV int node_wanted() const { return ts.cur; }
-  RT_DEV void step_leaf(const scene_view& sv, lane_counters& k) { ts.step_leaf(sv, k); }
+  RT_DEV void step_leaf(const scene_dev& sc, const scene_view& sv, lane_counters& k) { ts.step_leaf(sc, sv, k); }
   RT_DEV void finish(const scene_dev& sc, const scene_view& sv, float& t, int& idx, lane_counters& k) {
     if (!T::tree) {  // the scan is the search
       hit_linear<COUNTED>(sv.scan_sph, sc.n_spheres, ts.o, ts.d, t, idx, k);
+      if (T::quads) hit_quads_linear(sc, ts.o, ts.d, t, idx);
       return;
     }
     ts.finish(sc, sv, t, idx, k);
@@ -328,6 +333,10 @@ RT_DEV bool shade_finished(searcher<SEARCH, COUNTED>& srch, const scene_dev& sc,
     hit_rec h;
     h.point = o + d * t;
     h.normal = sv.inv_r[idx] * (h.point - mk3(sp.x, sp.y, sp.z));
+    if (search_traits<SEARCH>::quads && sp.w == -__builtin_inff()) {  // a quad: its plane's unit normal
+      const float4 qn = sc.quad_n[sc.quad_of[idx]];
+      h.normal = mk3(qn.x, qn.y, qn.z);
+    }
     h.interior = false;
     if (dot3(h.normal, d) >= 0.0f) {
       h.normal = -h.normal;
@@ -480,7 +489,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       if (srch.leaf_steps && (__ballot(node_lane) == 0ull || __popcll(__ballot(leaf_lane)) >= A.leaf_vote)) {
         RT_COUNT(k, leaf_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
         RT_COUNT(k, leaf_lane_steps, leaf_lane ? 1u : 0u);
-        if (leaf_lane) srch.step_leaf(sv, k);
+        if (leaf_lane) srch.step_leaf(sc, sv, k);
       } else {
         RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
         RT_COUNT(k, trav_lane_steps, node_lane ? 1u : 0u);
@@ -669,7 +678,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       if (srch.leaf_steps && (__ballot(node_lane) == 0ull || __popcll(__ballot(leaf_lane)) >= A.leaf_vote)) {
         RT_COUNT(k, leaf_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
         RT_COUNT(k, leaf_lane_steps, leaf_lane ? 1u : 0u);
-        if (leaf_lane) srch.step_leaf(sv, k);
+        if (leaf_lane) srch.step_leaf(sc, sv, k);
       } else {
         RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
         RT_COUNT(k, trav_lane_steps, node_lane ? 1u : 0u);
@@ -929,7 +938,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       if (srch.leaf_steps && (__ballot(node_lane) == 0ull || __popcll(__ballot(leaf_lane)) >= A.leaf_vote)) {
         RT_COUNT(k, leaf_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
         RT_COUNT(k, leaf_lane_steps, leaf_lane ? 1u : 0u);
-        if (leaf_lane) srch.step_leaf(sv, k);
+        if (leaf_lane) srch.step_leaf(sc, sv, k);
       } else {
         RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
         RT_COUNT(k, trav_lane_steps, node_lane ? 1u : 0u);
@@ -957,6 +966,10 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
         const float4 sp = sv.sph[idx];
         const f3 p = o + d * t;
         n = sv.inv_r[idx] * (p - mk3(sp.x, sp.y, sp.z));
+        if (search_traits<SEARCH>::quads && sp.w == -__builtin_inff()) {
+          const float4 qn = sc.quad_n[sc.quad_of[idx]];
+          n = mk3(qn.x, qn.y, qn.z);
+        }
         if (dot3(n, d) >= 0.0f) n = -n;
         id = idx;
         tt = t;

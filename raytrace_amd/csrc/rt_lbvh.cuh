@@ -125,6 +125,12 @@ __device__ __forceinline__ box3 sphere_box(const float4* leaf_sph, const float* 
   return b;
 }
 
+// The radius bound a leaf brings to the box-growing rule: a sphere's radius; 0 for a quad (a leaf whose record's
+// fourth word is -infinity, see quad_dev), whose box is the cube round its bounding sphere.
+__device__ __forceinline__ float leaf_rmin(const float4* leaf_sph, const float* leaf_r, int kpos) {
+  return leaf_sph[kpos].w == -__builtin_inff() ? 0.0f : fabsf(leaf_r[kpos]);
+}
+
 // Gather the spheres into Morton order.
 __global__ __launch_bounds__(256) void lbvh_gather_kernel(const float4* sph, const float* radius, const int32_t* upload_index,
                                                           const uint32_t* sorted_index, int n, float4* leaf_sph,
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(256) void lbvh_fit_kernel(const float4* leaf_sph, c
       box3 cb;
       if (c < 0) {
         cb = sphere_box(leaf_sph, leaf_r, ~c);
-        rmin = fminf(rmin, fabsf(leaf_r[~c]));
+        rmin = fminf(rmin, leaf_rmin(leaf_sph, leaf_r, ~c));
       } else {
         rmin = fminf(rmin, __hip_atomic_load(node_rmin + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         const float* src = node_box + 6 * (size_t)c;
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(256) void lbvh_collapse_kernel(const float4* leaf_s
       if (c < 0) {
         b = sphere_box(leaf_sph, leaf_r, ~c);
         nd.ref[s] = c;
-        nd.rmin[s] = fabsf(leaf_r[~c]);
+        nd.rmin[s] = leaf_rmin(leaf_sph, leaf_r, ~c);
       } else {
         nd.rmin[s] = node_rmin[c];
 #pragma unroll

@@ -49,6 +49,17 @@ struct scene_dev {
   const float4* mat_a;      // (albedo.r, albedo.g, albedo.b, param1)
   const int32_t* mat_type;
   perlin_table noise;       // gradient table of the noise-textured material (null without one)
+  // --- quads (scenes uploaded with rt_scene_upload_objects; none otherwise) ---
+  // An object that is a quad has, in the arrays above, the record (0, 0, 0, -infinity) — a sphere no ray hits —
+  // 1/r = 0, its material, and its number among the quads in quad_of.
+  int32_t n_quads;
+  const float4* quad_qd;    // per quad: (Q, D)
+  const float4* quad_u;     // (u, -)
+  const float4* quad_v;     // (v, -)
+  const float4* quad_n;     // (unit normal, -)
+  const float4* quad_w;     // (w, -)
+  const int32_t* quad_idx;  // quad -> upload index, ascending
+  const int32_t* quad_of;   // upload index -> quad, or -1
   // --- hierarchy (unused by the linear scan) ---
   // Spheres much larger than the rest are kept out of the tree and tested
   // exactly for every ray: their boxes would swallow the whole tree.
@@ -233,6 +244,32 @@ RT_DEV void hit_linear(const float4* sph, int n, f3 o, f3 d, float& t_out, int& 
   i_out = best_i;
 }
 
+RT_DEV quad_dev load_quad(const scene_dev& sc, int qi) {
+  quad_dev q;
+  const float4 a = sc.quad_qd[qi], u = sc.quad_u[qi], v = sc.quad_v[qi], n = sc.quad_n[qi], w = sc.quad_w[qi];
+  q.Q = mk3(a.x, a.y, a.z);
+  q.D = a.w;
+  q.u = mk3(u.x, u.y, u.z);
+  q.v = mk3(v.x, v.y, v.z);
+  q.normal = mk3(n.x, n.y, n.z);
+  q.w = mk3(w.x, w.y, w.z);
+  return q;
+}
+
+// The quads of a scene against a result of the scan over its spheres (best_t > 0.001: a hit at sphere best_i).
+// Quads are tested after all spheres and a quad replaces the result if it is nearer, or as near with a lower upload
+// index: the closest object, ties to the one uploaded first, as among spheres.
+RT_DEV void hit_quads_linear(const scene_dev& sc, f3 o, f3 d, float& best_t, int& best_i) {
+  for (int qi = 0; qi < sc.n_quads; qi++) {
+    const float t = hit_quad(load_quad(sc, qi), o, d);
+    const int idx = sc.quad_idx[qi];
+    if (t > 0.001f && (!(best_t > 0.001f) || t < best_t || (t == best_t && idx < best_i))) {
+      best_t = t;
+      best_i = idx;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Hierarchy traversal.
 //
@@ -311,6 +348,15 @@ RT_DEV void consider_sphere(float4 s, int upload_index, f3 o, f3 d, float a, tra
       c.best_t = t;
       c.best_i = upload_index;
     }
+  }
+}
+
+// The same for a quad leaf (trees of scenes with quads).
+RT_DEV void consider_quad(const scene_dev& sc, int upload_index, f3 o, f3 d, trav_candidate& c) {
+  const float t = hit_quad(load_quad(sc, sc.quad_of[upload_index]), o, d);
+  if (t > 0.001f && (t < c.best_t || (t == c.best_t && upload_index < c.best_i))) {
+    c.best_t = t;
+    c.best_i = upload_index;
   }
 }
 
@@ -540,7 +586,7 @@ RT_DEV int pick_ref(int4 ref, unsigned mask) {
 //   step_leaf()  exact test of one queued leaf
 //   active()     false when the search is over
 //   finish()     the scan's answer (repeats the ray with the scan when flagged)
-template <bool PAD_RAY, bool PACKED, int STACK, bool COUNTED>
+template <bool PAD_RAY, bool PACKED, int STACK, bool COUNTED, bool QUADS = false>
 struct tree_search {
   f3 o, d;
   float a;
@@ -587,18 +633,25 @@ struct tree_search {
         return false;
       }
     }
-    if (sc.root < 0) {  // a single sphere in the tree
-      consider_sphere<COUNTED>(sv.leaf_sph[~sc.root], sv.leaf_idx[~sc.root], o, d, a, c, k);
+    if (sc.root < 0) {  // a single leaf in the tree
+      consider_leaf(sc, sv, ~sc.root, k);
       return false;
     }
     cur = sc.root;
     return true;
   }
 
-  RT_DEV void step_leaf(const scene_view& sv, lane_counters& k) {
-    const int pos = lq.pop();
-    consider_sphere<COUNTED>(sv.leaf_sph[pos], sv.leaf_idx[pos], o, d, a, c, k);
+  // Exact test of the leaf at a position of the tree's order: a sphere, or (scenes with quads) a quad.
+  RT_DEV void consider_leaf(const scene_dev& sc, const scene_view& sv, int pos, lane_counters& k) {
+    const float4 rec = sv.leaf_sph[pos];
+    if (QUADS && rec.w == -__builtin_inff()) {
+      RT_COUNT(k, sphere_tests, 1);
+      consider_quad(sc, sv.leaf_idx[pos], o, d, c);
+    } else {
+      consider_sphere<COUNTED>(rec, sv.leaf_idx[pos], o, d, a, c, k);
+    }
   }
+  RT_DEV void step_leaf(const scene_dev& sc, const scene_view& sv, lane_counters& k) { consider_leaf(sc, sv, lq.pop(), k); }
 
   // `staged`: where stage_nodes() put this lane's node (trees read from HBM; unused when the
   // whole tree is in LDS).
@@ -787,6 +840,7 @@ struct tree_search {
   RT_DEV void finish(const scene_dev& sc, const scene_view& sv, float& t_out, int& i_out, lane_counters& k) {
     if (c.redo()) {
       hit_linear_lean<COUNTED>(sv.scan_sph, sc.n_spheres, o, d, t_out, i_out, k);
+      if (QUADS) hit_quads_linear(sc, o, d, t_out, i_out);
       return;
     }
     t_out = c.best_i >= 0 ? c.best_t : -1.0f;

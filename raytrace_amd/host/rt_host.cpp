@@ -69,7 +69,10 @@ inline float hash01(uint32_t seed, uint64_t i, uint32_t k) {
 
 struct counts {
   int spheres, materials;
+  int object_bytes = 0;  // hittable_list::offset, for lists whose records differ in size
 };
+
+thread_local int g_object_bytes = 0;
 
 // glGenBuffers + glBufferData of raytrace.cpp:381-386 / 416-421.
 void allocate_buffers(size_t slots) {
@@ -198,6 +201,66 @@ counts scene_cloud(int n, uint32_t seed) {
   return {objects.num, materials.num};
 }
 
+// A room of five quads (walls, floor, ceiling; open towards the camera) with three spheres in it.
+counts scene_quad_room() {
+  allocate_buffers(MAX_NUM_OBJECTS);
+  material_list materials;
+  hittable_list objects;
+  lambertian red(colour(0.65, 0.05, 0.05)), white(colour(0.73, 0.73, 0.73)), green(colour(0.12, 0.45, 0.15));
+  lambertian blue(colour(0.2, 0.2, 0.8));
+  metallic mirror(colour(0.8, 0.85, 0.88), 0.0), brushed(colour(0.7, 0.6, 0.5), 0.3);
+  dialectric glass(1.5);
+  for (material* m : {(material*)&red, (material*)&white, (material*)&green, (material*)&blue, (material*)&mirror,
+                      (material*)&brushed, (material*)&glass})
+    materials.add(RT_HOST_MATERIAL_BUFFER, *m);
+  quad left(point3(-3, -2, 1), vec3(0, 0, -6), vec3(0, 4, 0), &red);
+  quad back(point3(-3, -2, -5), vec3(6, 0, 0), vec3(0, 4, 0), &mirror);
+  quad right(point3(3, -2, -5), vec3(0, 0, 6), vec3(0, 4, 0), &green);
+  quad ceiling(point3(-3, 2, -5), vec3(6, 0, 0), vec3(0, 0, 6), &white);
+  quad floor_(point3(-3, -2, 1), vec3(6, 0, 0), vec3(0, 0, -6), &white);
+  quad slanted(point3(-1.5, -2, -3.5), vec3(1.5, 0, 1.0), vec3(0.3, 2.5, -0.4), &blue);
+  sphere ball(0.8, point3(1.2, -1.2, -2.5), &glass);
+  sphere ball2(0.6, point3(-1.4, -1.4, -1.2), &brushed);
+  sphere bubble(-0.7, point3(1.2, -1.2, -2.5), &glass);
+  objects.add(RT_HOST_SPHERE_BUFFER, left);
+  objects.add(RT_HOST_SPHERE_BUFFER, ball);
+  objects.add(RT_HOST_SPHERE_BUFFER, back);
+  objects.add(RT_HOST_SPHERE_BUFFER, right);
+  objects.add(RT_HOST_SPHERE_BUFFER, ball2);
+  objects.add(RT_HOST_SPHERE_BUFFER, ceiling);
+  objects.add(RT_HOST_SPHERE_BUFFER, floor_);
+  objects.add(RT_HOST_SPHERE_BUFFER, bubble);
+  objects.add(RT_HOST_SPHERE_BUFFER, slanted);
+  return {objects.num, materials.num, objects.offset};
+}
+
+// n objects uniform in [-50,50)^3: every third one a quad with edges of up to 4 units, the others spheres of
+// radius [0.1,1); four materials.
+counts scene_quad_cloud(int n, uint32_t seed) {
+  allocate_buffers((size_t)n * 2);
+  material_list materials;
+  hittable_list objects;
+  lambertian grey(colour(0.5, 0.5, 0.5)), warm(colour(0.8, 0.5, 0.3));
+  metallic metal(colour(0.7, 0.7, 0.8), 0.1);
+  dialectric glass(1.5);
+  material* mats[4] = {&grey, &warm, &metal, &glass};
+  for (material* m : mats) materials.add(RT_HOST_MATERIAL_BUFFER, *m);
+  for (int i = 0; i < n; i++) {
+    auto h = [&](uint32_t k) { return hash01(seed, (uint64_t)i, k); };
+    const point3 c(-50.0f + 100.0f * h(0), -50.0f + 100.0f * h(1), -50.0f + 100.0f * h(2));
+    material* m = mats[(int)(h(3) * 4.0f) & 3];
+    if (i % 3 == 1) {
+      quad q(c, vec3(-2.0f + 4.0f * h(4), -2.0f + 4.0f * h(5), -2.0f + 4.0f * h(6)),
+             vec3(-2.0f + 4.0f * h(7), -2.0f + 4.0f * h(8), -2.0f + 4.0f * h(9)), m);
+      objects.add(RT_HOST_SPHERE_BUFFER, q);
+    } else {
+      sphere s(0.1f + 0.9f * h(4), c, m);
+      objects.add(RT_HOST_SPHERE_BUFFER, s);
+    }
+  }
+  return {objects.num, materials.num, objects.offset};
+}
+
 }  // namespace
 
 extern "C" {
@@ -266,6 +329,12 @@ int rt_host_scene_camera(int scene, rt_camera* out) {
     case RT_SCENE_CLOUD:
       set(point3(0, 0, 900), point3(0, 0, 0), vec3(0, 1, 0), 40.0, 0.0, 10.0, 0);
       return RT_OK;
+    case RT_SCENE_QUAD_ROOM:
+      set(point3(0, 0, 6), point3(0, 0, -2), vec3(0, 1, 0), 50.0, 0.0, 8.0, 0);
+      return RT_OK;
+    case RT_SCENE_QUAD_CLOUD:
+      set(point3(0, 0, 120), point3(0, 0, 0), vec3(0, 1, 0), 45.0, 0.0, 10.0, 0);
+      return RT_OK;
   }
   return RT_ERR_INVALID;
 }
@@ -281,11 +350,19 @@ int rt_host_build_scene(int scene, int n, uint32_t seed, int* n_materials) {
       if (n < 1) return RT_ERR_INVALID;
       c = scene_cloud(n, seed);
       break;
+    case RT_SCENE_QUAD_ROOM: c = scene_quad_room(); break;
+    case RT_SCENE_QUAD_CLOUD:
+      if (n < 1) return RT_ERR_INVALID;
+      c = scene_quad_cloud(n, seed);
+      break;
     default: return RT_ERR_INVALID;
   }
   if (n_materials) *n_materials = c.materials;
+  g_object_bytes = c.object_bytes ? c.object_bytes : c.spheres * RT_RECORD_BYTES;
   return c.spheres;
 }
+
+int rt_host_scene_object_bytes(void) { return g_object_bytes; }
 
 int rt_host_gen_rays(uint32_t seed, uint64_t first, size_t n, float* o_xyz, float* d_xyz) {
   if (!o_xyz || !d_xyz) return RT_ERR_INVALID;

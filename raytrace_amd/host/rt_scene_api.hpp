@@ -12,6 +12,7 @@
 //   hittable.h:6-15            hittable
 //   hittable_list.h:6-21       hittable_list
 //   sphere.h:11-36             sphere
+//   (none; extension)          quad
 //   material.h:9-65            MATERIAL_TYPE, material, lambertian, metallic, dialectric
 //   material_list.h:6-22       material_list
 // The writes go to rt_gl_bind_buffer / rt_gl_buffer_sub_data (raytrace_amd.h),
@@ -220,6 +221,28 @@ class sphere : public hittable {
     put(glBuffer, offset + 0, sizeof(int), &mat->id);
     put(glBuffer, offset + 4, sizeof(float), &radius);
     put(glBuffer, offset + 16, 3 * sizeof(float), origin.e);
+  }
+};
+
+// Extension: a parallelogram with corner Q and edges u and v, the second subclass of hittable.
+// Record layout (64 bytes): material id @0, RT_OBJECT_QUAD @8, Q @16, u @32, v @48.  Lists that hold one
+// are handed to rt_scene_upload_objects with hittable_list::offset as the byte count.
+class quad : public hittable {
+ public:
+  vec3 Q, u, v;
+  material* mat = nullptr;
+
+  quad() {}
+  quad(vec3 corner, vec3 edge_u, vec3 edge_v, material* m) : hittable{RT_QUAD_RECORD_BYTES}, Q{corner}, u{edge_u}, v{edge_v}, mat{m} {}
+
+  void add(unsigned int glBuffer, int offset) const override {
+    using rt_scene_detail::put;
+    const int kind = RT_OBJECT_QUAD;
+    put(glBuffer, offset + 0, sizeof(int), &mat->id);
+    put(glBuffer, offset + 8, sizeof(int), &kind);
+    put(glBuffer, offset + 16, 3 * sizeof(float), Q.e);
+    put(glBuffer, offset + 32, 3 * sizeof(float), u.e);
+    put(glBuffer, offset + 48, 3 * sizeof(float), v.e);
   }
 };
 
