@@ -15,4 +15,4 @@ for g in "${groups[@]}"; do
   timeout -s KILL 120 rocprofv3 --pmc $g --output-format csv -d $out -o g$i -- python3 $GRAFT_REPO_ROOT/tools/quick_c2.py --no-check --frames 1 "$@" > $out/g$i.stdout 2> $out/g$i.stderr || { echo "group $i failed"; tail -3 $out/g$i.stderr; exit 1; }
   i=$((i+1))
 done
-python3 $GRAFT_REPO_ROOT/tools/pmc_report.py $out rt_render_kernel | tee $out/summary.txt
+python3 $GRAFT_REPO_ROOT/tools/pmc_report.py $out rt_render_ | tee $out/summary.txt
