@@ -883,6 +883,21 @@ bool attach_overflow_fixed(rt_ctx* c, long long& blocks, scene_dev& sc, unsigned
   return true;
 }
 
+// Workgroups of a render launch: as many as stay resident, and no more than the work can occupy.  A wave takes 64 work
+// items at a time: the pixels of an 8x8 tile, or 64 jobs — a pixel's sweeps in a pass in sweeps, and in a main pass
+// with a job list more jobs than resident lanes whatever the tile's size (the plan cuts the pixels until there are),
+// so that a small tile still fills the device.
+template <int WAVES>
+long long blocks_for(const rt_ctx* c, int per_cu, int tw, int th, const render_args& a) {
+  long long blocks = (long long)per_cu * c->n_cu;
+  if (a.jobs == nullptr) {
+    const long long tiles = (long long)((tw + 7) / 8) * ((th + 7) / 8) * (a.sweeps > 1 ? a.sweeps : 1);
+    const long long needed = (tiles + WAVES - 1) / WAVES;
+    if (blocks > needed) blocks = needed;
+  }
+  return blocks < 1 ? 1 : blocks;
+}
+
 template <int SEARCH, int RNG, bool COUNTED>
 hipError_t launch_render_one(rt_ctx* c, const rt_params* p, hipStream_t st, render_args a) {
   using T = search_traits<SEARCH>;
@@ -894,11 +909,7 @@ hipError_t launch_render_one(rt_ctx* c, const rt_params* p, hipStream_t st, rend
   e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_kernel<SEARCH, RNG, COUNTED>, T::threads, lds);
   if (e != hipSuccess) return e;
   if (per_cu < 1) per_cu = 1;
-  const long long tiles = (long long)((tw + 7) / 8) * ((th + 7) / 8);
-  long long blocks = (long long)per_cu * c->n_cu;
-  const long long needed = (tiles + T::waves - 1) / T::waves;
-  if (blocks > needed) blocks = needed;
-  if (blocks < 1) blocks = 1;
+  const long long blocks = blocks_for<T::waves>(c, per_cu, tw, th, a);
   e = attach_overflow<SEARCH>(c, blocks, a.sc);
   if (e != hipSuccess) return e;
   rt_render_kernel<SEARCH, RNG, COUNTED><<<dim3((unsigned)blocks), T::threads, lds, st>>>(a);
@@ -923,11 +934,7 @@ hipError_t launch_stored_one(rt_ctx* c, hipStream_t st, render_args a) {
   e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_stored_kernel<SEARCH, COUNTED>, T::threads, lds);
   if (e != hipSuccess) return e;
   if (per_cu < 1) per_cu = 1;
-  const long long tiles = (long long)((tw + 7) / 8) * ((th + 7) / 8);
-  long long blocks = (long long)per_cu * c->n_cu;
-  const long long needed = (tiles + T::waves - 1) / T::waves;
-  if (blocks > needed) blocks = needed;
-  if (blocks < 1) blocks = 1;
+  const long long blocks = blocks_for<T::waves>(c, per_cu, tw, th, a);
   e = attach_overflow<SEARCH>(c, blocks, a.sc);
   if (e != hipSuccess) return e;
   rt_render_stored_kernel<SEARCH, COUNTED><<<dim3((unsigned)blocks), T::threads, lds, st>>>(a);
