@@ -27,6 +27,9 @@ enum {
 #define RT_TRACE_WAVES 5
 #endif
 #ifndef RT_JOB_CHUNK
+#ifndef RT_LDS_STACK
+#define RT_LDS_STACK 12    // traversal-stack entries per lane for trees held in LDS (a deeper chain sends the ray to the scan)
+#endif
 #define RT_JOB_CHUNK 64u   // pixels / jobs a wave takes from the queue per atomic (more when more lanes ask at once)
 #endif
 #ifndef RT_LINEAR_WAVES
@@ -42,7 +45,7 @@ struct search_traits {
   static constexpr bool pad_ray = SEARCH == SEARCH_TREE_LDS_RAY || SEARCH == SEARCH_TREE_GLB_RAY;
   static constexpr int waves = lds ? 16 : 4;       // waves per workgroup
   static constexpr int threads = waves * 64;
-  static constexpr int stack = lds ? 12 : 8;       // entries per lane kept in LDS
+  static constexpr int stack = lds ? RT_LDS_STACK : 8;  // entries per lane kept in LDS
   // per wave: one word per entry and lane; above the last row, three rows of slack for trees in LDS (a node step
   // stores three keys above the top whatever it pushes), one row for the others (the sink of stores that do not fit)
   static constexpr int stack_words = !tree ? 0 : (stack + (lds ? 3 : 1)) * 64;
