@@ -48,7 +48,8 @@ struct search_traits {
   static constexpr int stack = lds ? RT_LDS_STACK : 8;  // entries per lane kept in LDS
   // per wave: one word per entry and lane; above the last row, three rows of slack for trees in LDS (a node step
   // stores three keys above the top whatever it pushes), one row for the others (the sink of stores that do not fit)
-  static constexpr int stack_words = !tree ? 0 : (stack + (lds ? 3 : 1)) * 64;
+  // (trees read from HBM: above the sink row, the rows of the lane's leaf queue)
+  static constexpr int stack_words = !tree ? 0 : (stack + (lds ? 3 : 1 + RT_LEAF_ROWS)) * 64;
   // trees read from HBM pass their nodes through a per-wave staging area in LDS (stage_nodes)
   static constexpr bool staged = tree && !lds;
   static constexpr int stage_bytes = staged ? RT_STAGE_BYTES : 0;
@@ -215,7 +216,9 @@ RT_DEV void search_setup(const scene_dev& sc, scene_view& sv, uint32_t*& stack_c
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   stack_col = reinterpret_cast<uint32_t*>(base) + wave * T::stack_words + lane;
-  if (T::staged) stage = (uint32_t)(T::waves * T::stack_words * 4 + wave * T::stage_bytes);  // no scene copy precedes the stacks
+  // (no scene copy precedes the stacks; the offset is the same for the whole wave, and saying so keeps the LDS base of
+  // the staging loads in a scalar register)
+  if (T::staged) stage = (uint32_t)__builtin_amdgcn_readfirstlane((int)(T::waves * T::stack_words * 4 + wave * T::stage_bytes));
   if (!T::lds && sc.ovf != nullptr) {
     sv.ovf_col = sc.ovf + ((size_t)blockIdx.x * T::waves + wave) * (size_t)sc.ovf_cap * 64 + lane;
     sv.ovf_cap = sc.ovf_cap;
@@ -252,7 +255,9 @@ struct searcher {
     ts.step_node(sv, stk, staged, k);
   }
   RT_DEV int node_wanted() const { return ts.cur; }
-  RT_DEV void step_leaf(const scene_dev& sc, const scene_view& sv, lane_counters& k) { ts.step_leaf(sc, sv, k); }
+  RT_DEV void step_leaf(const scene_dev& sc, const scene_view& sv, const uint32_t* stack_col, lane_counters& k) {
+    ts.step_leaf(sc, sv, stack_col + (T::stack + 1) * 64, k);
+  }
   RT_DEV void finish(const scene_dev& sc, const scene_view& sv, float& t, int& idx, lane_counters& k) {
     if (!T::tree) {  // the scan is the search
       hit_linear<COUNTED>(sv.scan_sph, sc.n_spheres, ts.o, ts.d, t, idx, k);
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       if (srch.leaf_steps && (__ballot(node_lane) == 0ull || __popcll(__ballot(leaf_lane)) >= A.leaf_vote)) {
         RT_COUNT(k, leaf_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
         RT_COUNT(k, leaf_lane_steps, leaf_lane ? 1u : 0u);
-        if (leaf_lane) srch.step_leaf(sc, sv, k);
+        if (leaf_lane) srch.step_leaf(sc, sv, stack_col, k);
       } else {
         RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
         RT_COUNT(k, trav_lane_steps, node_lane ? 1u : 0u);
@@ -681,7 +686,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       if (srch.leaf_steps && (__ballot(node_lane) == 0ull || __popcll(__ballot(leaf_lane)) >= A.leaf_vote)) {
         RT_COUNT(k, leaf_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
         RT_COUNT(k, leaf_lane_steps, leaf_lane ? 1u : 0u);
-        if (leaf_lane) srch.step_leaf(sc, sv, k);
+        if (leaf_lane) srch.step_leaf(sc, sv, stack_col, k);
       } else {
         RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
         RT_COUNT(k, trav_lane_steps, node_lane ? 1u : 0u);
@@ -941,7 +946,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       if (srch.leaf_steps && (__ballot(node_lane) == 0ull || __popcll(__ballot(leaf_lane)) >= A.leaf_vote)) {
         RT_COUNT(k, leaf_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
         RT_COUNT(k, leaf_lane_steps, leaf_lane ? 1u : 0u);
-        if (leaf_lane) srch.step_leaf(sc, sv, k);
+        if (leaf_lane) srch.step_leaf(sc, sv, stack_col, k);
       } else {
         RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
         RT_COUNT(k, trav_lane_steps, node_lane ? 1u : 0u);

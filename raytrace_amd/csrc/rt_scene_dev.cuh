@@ -488,11 +488,9 @@ RT_DEV uint32_t stage_nodes(const bvh4q_node* nodes, int my_node, uint32_t stage
   // loads that write LDS directly: each lane gives its own source address; the 64 x 16 bytes land
   // side by side from the row start
 #pragma unroll
-  for (int p = 0; p < G; p++) {
-    if (w[p] >= 0)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)w[p] * sizeof(bvh4q_node)),
-                                       (__attribute__((address_space(3))) void*)(stage + p * RT_STAGE_ROW), 16, 0, 0);
-  }
+  for (int p = 0; p < G; p++)  // (a pass nobody wants reads node 0: cheaper than a branch per pass)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)max(w[p], 0) * sizeof(bvh4q_node)),
+                                     (__attribute__((address_space(3))) void*)(stage + p * RT_STAGE_ROW), 16, 0, 0);
 #else
   // through registers: all loads first (a pass nobody wants reads node 0), then the stores
   float4 piece[G];
@@ -526,9 +524,9 @@ struct trav_stack {
 };
 
 // Leaves whose box a node step found worth testing wait here until the wave
-// takes a leaf step: six Morton positions (stored +1, zero = empty slot) per
-// lane, 10 bits each in one word when the tree is the LDS-resident kind (at
-// most 1022 leaves), 32 bits each in three words otherwise.
+// takes a leaf step: Morton positions, six of 10 bits each (stored +1, zero = empty slot) in one
+// word when the tree is the LDS-resident kind (at most 1022 leaves), RT_LEAF_ROWS words in LDS otherwise.
+#define RT_LEAF_ROWS 5
 template <bool PACKED>
 struct leaf_queue;
 
@@ -539,8 +537,10 @@ struct leaf_queue<true> {
   RT_DEV void clear() { q = 0ull; }
   RT_DEV bool empty() const { return q == 0ull; }
   RT_DEV bool room_for_node() const { return (q >> 20) == 0ull; }  // at most two waiting: four more fit
-  RT_DEV void push(int pos) { q = (q << 10) | (unsigned long long)(pos + 1); }
-  RT_DEV int pop() {
+  RT_DEV void push_if(uint32_t*, bool leaf, int pos) {
+    if (leaf) q = (q << 10) | (unsigned long long)(pos + 1);
+  }
+  RT_DEV int pop(const uint32_t*) {
     const int pos = (int)(q & 1023ull) - 1;
     q >>= 10;
     return pos;
@@ -549,21 +549,22 @@ struct leaf_queue<true> {
 
 template <>
 struct leaf_queue<false> {
-  unsigned long long a, b, c;  // two 32-bit entries each, a the newest pair
-  RT_DEV void clear() { a = b = c = 0ull; }
-  RT_DEV bool empty() const { return a == 0ull; }
-  RT_DEV bool room_for_node() const { return (b | c) == 0ull; }
-  RT_DEV void push(int pos) {
-    c = (c << 32) | (b >> 32);
-    b = (b << 32) | (a >> 32);
-    a = (a << 32) | (unsigned long long)(uint32_t)(pos + 1);
+  // Trees read from HBM: the waiting leaves lie in rows of the lane's LDS column above its stack rows (`rows`), and
+  // only their number lives in a register.  A push is a store and an add with carry whatever the lane's case — the
+  // slot above the last leaf takes what a lane has no leaf for — where a queue shifted through registers cost a
+  // branch and eight moves per child of every node.
+  static constexpr int cap = RT_LEAF_ROWS;
+  int n;
+  RT_DEV void clear() { n = 0; }
+  RT_DEV bool empty() const { return n == 0; }
+  RT_DEV bool room_for_node() const { return n <= cap - 4; }
+  RT_DEV void push_if(uint32_t* rows, bool leaf, int pos) {
+    rows[n * 64] = (uint32_t)pos;
+    n += leaf ? 1 : 0;
   }
-  RT_DEV int pop() {
-    const int pos = (int)(uint32_t)a - 1;
-    a = (a >> 32) | (b << 32);
-    b = (b >> 32) | (c << 32);
-    c >>= 32;
-    return pos;
+  RT_DEV int pop(const uint32_t* rows) {
+    n--;
+    return (int)rows[n * 64];
   }
 };
 
@@ -651,7 +652,10 @@ struct tree_search {
       consider_sphere<COUNTED>(rec, sv.leaf_idx[pos], o, d, a, c, k);
     }
   }
-  RT_DEV void step_leaf(const scene_dev& sc, const scene_view& sv, lane_counters& k) { consider_leaf(sc, sv, lq.pop(), k); }
+  // `leaf_rows`: the lane's queue rows (leaf_queue; trees read from HBM)
+  RT_DEV void step_leaf(const scene_dev& sc, const scene_view& sv, const uint32_t* leaf_rows, lane_counters& k) {
+    consider_leaf(sc, sv, lq.pop(leaf_rows), k);
+  }
 
   // `staged`: where stage_nodes() put this lane's node (trees read from HBM; unused when the
   // whole tree is in LDS).
@@ -743,8 +747,8 @@ struct tree_search {
       RT_COUNT(k, node_tests, refs[ch] != RT_REF_EMPTY ? 1u : 0u);
       if (LEAF_INLINE) {
         leaf_mask |= (ok[ch] & (refs[ch] < 0)) ? (1u << ch) : 0u;  // a select on combined lane masks, not a branch per child
-      } else if (ok[ch] && refs[ch] < 0) {
-        lq.push(~refs[ch]);
+      } else {
+        lq.push_if(stk.col + (STACK + 1) * 64, ok[ch] & (refs[ch] < 0), ~refs[ch]);
       }
     }
     // LDS-resident scenes test the leaves here and now (an exact hit shortens the ray for what is popped later, and a
