@@ -464,24 +464,28 @@ RT_DEV float byte_of(uint32_t w, int ch) { return (float)((w >> (8 * ch)) & 255u
 #define RT_STAGE_DMA 1
 #endif
 #define RT_STAGE_ROW 1040   // 64 lanes x 16 bytes + 16: the rows start in different banks
-#define RT_STAGE_BYTES (RT_STAGE_PIECES * RT_STAGE_ROW + 256)
+#define RT_STAGE_BYTES (RT_STAGE_PIECES * RT_STAGE_ROW + (RT_STAGE_PIECES == 4 ? 0 : 256))  // (+ the wanted list of groups of eight)
 extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds[];
 RT_DEV uint32_t stage_nodes(const bvh4q_node* nodes, int my_node, uint32_t stage_offset) {
   constexpr int G = RT_STAGE_PIECES;  // lanes of a group = passes = staged pieces
   static_assert(G == 4 || G == 8, "a group reads 64 or 128 consecutive bytes");
   unsigned char* stage = rt_lds + stage_offset;
   const int lane = threadIdx.x & 63, sub = lane & (G - 1);
-  int* wanted = reinterpret_cast<int*>(stage + G * RT_STAGE_ROW);
-  wanted[lane] = my_node;
-  __builtin_amdgcn_wave_barrier();  // LDS operations of one wave execute in order
+  // what the lanes of this lane's group want: for groups of four a quad broadcast per pass (no LDS round trip)
   int w[G];
-  {
+  if (G == 4) {
+    w[0] = __builtin_amdgcn_mov_dpp(my_node, 0x00, 0xF, 0xF, true);  // quad_perm [0,0,0,0]
+    w[1] = __builtin_amdgcn_mov_dpp(my_node, 0x55, 0xF, 0xF, true);  // [1,1,1,1]
+    w[2] = __builtin_amdgcn_mov_dpp(my_node, 0xAA, 0xF, 0xF, true);  // [2,2,2,2]
+    w[3] = __builtin_amdgcn_mov_dpp(my_node, 0xFF, 0xF, 0xF, true);  // [3,3,3,3]
+  } else {
+    int* wanted = reinterpret_cast<int*>(stage + G * RT_STAGE_ROW);
+    wanted[lane] = my_node;
+    __builtin_amdgcn_wave_barrier();  // LDS operations of one wave execute in order
     const int4 w0 = *reinterpret_cast<const int4*>(wanted + (lane & ~(G - 1)));
     w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w;
-    if (G == 8) {
-      const int4 w1 = *reinterpret_cast<const int4*>(wanted + (lane & ~(G - 1)) + 4);
-      w[G - 4] = w1.x; w[G - 3] = w1.y; w[G - 2] = w1.z; w[G - 1] = w1.w;
-    }
+    const int4 w1 = *reinterpret_cast<const int4*>(wanted + (lane & ~(G - 1)) + 4);
+    w[G - 4] = w1.x; w[G - 3] = w1.y; w[G - 2] = w1.z; w[G - 1] = w1.w;
   }
   const unsigned char* base = reinterpret_cast<const unsigned char*>(nodes) + sub * 16;
 #if RT_STAGE_DMA
