@@ -1234,7 +1234,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       HIP_TRY(c->scan_temp.resize(scan_bytes > 0 ? scan_bytes : 1));
       HIP_TRY(hipMemsetAsync(c->plan_total.p, 0, sizeof(unsigned long long), c->stream));
       const unsigned grid = (n + 255) / 256;
-      rt_plan_cost_kernel<<<grid < 1024 ? grid : 1024, 256, 0, c->stream>>>(c->carry_cost.p, n, c->plan_total.p);
+      rt_plan_cost_kernel<<<grid < 256 ? grid : 256, 256, 0, c->stream>>>(c->carry_cost.p, n, c->plan_total.p);
       rt_plan_count_kernel<<<grid, 256, 0, c->stream>>>(c->carry_cost.p, c->order_idx.p, n, c->plan_total.p, lanes, max_split, main_samples,
                                                        splittable, fewest, c->plan_parts.p);
       HIP_TRY(hipGetLastError());

@@ -795,10 +795,17 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
 // cost[p] = segments the probe pass spent on rect pixel p; order[i] = the pixel at sorted position i.
 
 __global__ __launch_bounds__(256) void rt_plan_cost_kernel(const uint32_t* cost, uint32_t n, unsigned long long* total) {
+  __shared__ unsigned long long part[4];
   unsigned long long sum = 0;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) sum += cost[i];
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-  if ((threadIdx.x & 63) == 0 && sum != 0) atomicAdd(total, sum);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  // one atomic per workgroup: thousands of them on one address take longer than reading the costs
+  if (threadIdx.x == 0) {
+    sum = (part[0] + part[1]) + (part[2] + part[3]);
+    if (sum != 0) atomicAdd(total, sum);
+  }
 }
 
 // Jobs of the pixel at sorted position i: its share of the measured cost in units of 1/lanes of the
@@ -823,20 +830,32 @@ __global__ __launch_bounds__(256) void rt_plan_count_kernel(const uint32_t* cost
   if (i < n) parts[i] = plan_parts(cost[order[i]], *total, lanes, i, max_split, samples, splittable, min_parts);
 }
 
-// first[i] = exclusive prefix sum of parts.  Writes the jobs of pixel i and, from the last pixel, the job count.
+// first[i] = exclusive prefix sum of parts.  Writes the jobs of the pixels at sorted positions [256 b, 256 b + 256) — a
+// run of consecutive jobs — and, from the last workgroup, the job count.  Thread t writes jobs t, t + 256, ... of the
+// run (whole lines, side by side), finding each job's pixel by bisection of the workgroup's 257 prefix sums.
 __global__ __launch_bounds__(256) void rt_plan_jobs_kernel(const uint32_t* order, const uint32_t* parts, const uint32_t* first,
                                                           uint32_t n, int sample_begin, int sample_end, int all_rows, uint4* jobs,
                                                           uint32_t* n_jobs) {
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t k = parts[i], base = first[i];
+  __shared__ uint32_t start[257];
+  const uint32_t i0 = blockIdx.x * 256, i = i0 + threadIdx.x;
+  const uint32_t last = min(i0 + 256u, n) - 1u;  // the workgroup's last pixel
+  start[threadIdx.x] = i < n ? first[i] : 0xFFFFFFFFu;
+  if (threadIdx.x == 0) start[256] = first[last] + parts[last];
+  __syncthreads();
+  const uint32_t run_begin = start[0], run_end = start[256], count = last - i0 + 1u;
   const int samples = sample_end - sample_begin;
-  for (uint32_t j = 0; j < k; j++) {
-    const int s0 = sample_begin + (int)(((long long)samples * j) / k);
-    const int s1 = sample_begin + (int)(((long long)samples * (j + 1)) / k);
-    jobs[base + j] = make_uint4(order[i], (uint32_t)s0, (uint32_t)s1, (k > 1 || all_rows) ? i : RT_JOB_WHOLE);
+  for (uint32_t j = run_begin + threadIdx.x; j < run_end; j += 256u) {
+    uint32_t lo = 0, hi = count;  // the pixel lo with start[lo] <= j < start[lo + 1]
+    while (hi - lo > 1u) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (start[mid] <= j) lo = mid; else hi = mid;
+    }
+    const uint32_t pos = i0 + lo, k = parts[pos], part = j - start[lo];
+    const int s0 = sample_begin + (int)(((long long)samples * part) / k);
+    const int s1 = sample_begin + (int)(((long long)samples * (part + 1)) / k);
+    jobs[j] = make_uint4(order[pos], (uint32_t)s0, (uint32_t)s1, (k > 1 || all_rows) ? pos : RT_JOB_WHOLE);
   }
-  if (i == n - 1) *n_jobs = base + k;
+  if (last == n - 1u && threadIdx.x == 0) *n_jobs = run_end;
 }
 
 // Pixels that were cut into several jobs: the samples are added in sample order onto the sum the
