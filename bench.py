@@ -78,6 +78,8 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--bands", type=int, default=1, help="row bands per step whose sums overlap the next band's render (N > 1)")
+    ap.add_argument("--collective", choices=["gather", "reduce"], default="gather",
+                    help="strip shares (N > 1): gather each rank's rows onto rank 0, or sum whole accumulators")
     ap.add_argument("--no-extras", action="store_true", help="skip the linear-scan and weak-scaling legs")
     return ap.parse_args()
 
@@ -227,6 +229,7 @@ def main():
                             "accel": args.accel, "builder": info["builder"], "tree_nodes": info["n_nodes"], "node_bytes": info["node_bytes"],
                             "spheres": n_sph, "rays": n_rays_total, "lbvh_depth": r.lbvh_depth(), "ranks": world,
                             "parallelism": f"ray index ranges x{world}"}
+        result["_scaling"] = "strong"  # the batch is fixed; ranks take index ranges of it
         if accel == rt.ACCEL_LBVH:
             result["build_ms"] = r.last_build_ms()
     else:
@@ -254,17 +257,23 @@ def main():
 
         p, total_spp = share_params(strong)
 
-        def make_step(params):
+        def make_step(params, gather=None):
             def step(counted=False):
                 r.clear()  # memset + render are ordered on the library's own stream
-                if world > 1 and not counted:
+                if world > 1 and not counted and gather:
+                    # disjoint strips: every rank sends rank 0 the rows it rendered, queued behind the render on the device
+                    r.render(params)
+                    rtd.gather_rows(accum, gather, rank, dst=0, after=r)
+                elif world > 1 and not counted:
                     # render and RCCL sum onto rank 0, the sum queued behind the render on the device
                     rtd.render_and_combine(r, params, accum, dst=0, bands=args.bands)
                 else:
                     r.render(params, counted=counted)
             return step
 
-        step = make_step(p)
+        # strips over all ranks (the default job): disjoint rows, nothing to sum — rows are gathered, not reduced
+        strips_only = world > 1 and strong and not cfg.get("strong") and args.collective == "gather"
+        step = make_step(p, rtd.split_interleaved(h, total_spp, world) if strips_only else None)
         step(counted=True)
         counters = r.counters()
         units_per_step = w * h * total_spp
@@ -275,7 +284,8 @@ def main():
                             "accel": args.accel, "builder": info["builder"], "tree_nodes": info["n_nodes"], "tree_in_lds": bool(info["tree_in_lds"]),
                             "spheres": scene.n_spheres, "rng": cfg["rng"],
                             "lbvh_depth": r.lbvh_depth(), "global_samples_per_pixel": total_spp,
-                            "ranks": world, "collective": (f"{args.backend} reduce to rank 0, {args.bands} band(s) per step" if world > 1 else None),
+                            "ranks": world, "collective": (None if world == 1 else f"{args.backend} gather of each rank's rows onto rank 0" if strips_only else
+                                                           f"{args.backend} reduce to rank 0, {args.bands} band(s) per step"),
                             "parallelism": ("single GPU" if world == 1 else
                                             f"row bands x sample ranges over {world} ranks" if cfg.get("strong") else
                                             f"{world} interleaved sets of 8-row strips" if strong else f"sample ranges x{world}")}

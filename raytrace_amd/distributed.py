@@ -116,3 +116,60 @@ def render_and_combine(renderer, params, accum, dst: int = 0, bands: int = 4, gr
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream())
         torch.cuda.ExternalStream(renderer.stream()).wait_event(done)
+
+
+def share_rows(share: Share):
+    """The image rows a share covers, in increasing order."""
+    rows = range(share.y0, share.y1)
+    if share.strips:
+        rows = [y for y in rows if ((y - share.y0) // 8) % share.strips == share.strip]
+    return list(rows)
+
+
+_gather_cache = {}
+
+
+def gather_rows(accum, shares, rank: int, dst: int = 0, group=None, after=None):
+    """Shares with disjoint rows and the whole sample range each (strips, row bands): nothing has to be summed, so
+    every rank sends the root only the rows it rendered — 1/world of the frame instead of all of it — and the root
+    puts them in place.  `accum`: float32 [H, W, 3], device or CPU; `shares`: the shares of all ranks of the group,
+    the same list on every rank.  Ordered on the device like combine(): behind `after`'s queued work, no host wait
+    with the nccl backend; `after`'s stream is ordered behind the exchange, so its next clear cannot overtake it."""
+    import torch
+    import torch.distributed as dist
+    world = len(shares)
+    if any((s.s0, s.s1) != (shares[0].s0, shares[0].s1) for s in shares):
+        raise ValueError("gather_rows needs shares that differ in rows only")
+    device_ordered = accum.is_cuda and dist.get_backend(group) == "nccl"
+    key = (tuple(shares), tuple(accum.shape), str(accum.device), rank)
+    if key not in _gather_cache:
+        rows = [torch.tensor(share_rows(s), dtype=torch.long, device=accum.device) for s in shares]
+        seen = torch.cat(rows)
+        if seen.numel() != torch.unique(seen).numel():
+            raise ValueError("gather_rows needs disjoint shares")
+        most = max(int(r.numel()) for r in rows)
+        on_host = not device_ordered  # gloo: the exchange goes through host memory
+        send = torch.zeros((most,) + tuple(accum.shape[1:]), dtype=accum.dtype, device="cpu" if on_host else accum.device)
+        recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+        _gather_cache[key] = (rows, send, recv)
+    rows, send, recv = _gather_cache[key]
+    if after is not None and accum.is_cuda:
+        if device_ordered:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.ExternalStream(after.stream()))
+            torch.cuda.current_stream().wait_event(ev)
+        else:
+            after.synchronize()
+    mine = rows[rank]
+    send[:mine.numel()].copy_(accum.index_select(0, mine))
+    dist.gather(send, gather_list=recv, dst=dst, group=group)
+    if rank == dst:
+        for q in range(world):
+            if q != dst and rows[q].numel():
+                accum.index_copy_(0, rows[q], recv[q][:rows[q].numel()].to(accum.device))
+    if after is not None and accum.is_cuda and device_ordered:
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream())
+        torch.cuda.ExternalStream(after.stream()).wait_event(done)
+    elif accum.is_cuda:
+        torch.cuda.current_stream().synchronize()

@@ -45,6 +45,41 @@ def _worker(rank, world, port, row_groups, out_path):
     dist.destroy_process_group()
 
 
+def _gather_worker(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+    import oracle
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = rt.build_scene(rt.SCENE_RANDOM_SPHERES)
+    p = rt.make_params(rt.scene_camera(rt.SCENE_RANDOM_SPHERES), 40, 52, 4, rng_mode=rt.RNG_COUNTER)
+    shares = rtd.split_interleaved(p.height, 4, world)  # 52 rows: six and a half strips over three ranks
+    acc, _ = oracle.render(scene, rtd.apply_share(p, shares[rank]))
+    t = torch.from_numpy(acc)
+    for _ in range(2):  # the cached buffers serve a second frame
+        rtd.gather_rows(t, shares, rank, dst=0)
+    if rank == 0:
+        np.save(out_path, t.numpy())
+    dist.destroy_process_group()
+
+
+def test_three_ranks_gather_their_strips(tmp_path):
+    """Disjoint shares: each rank sends the root its own rows only; the frame is the one-call frame bit for bit."""
+    import torch.multiprocessing as mp
+    import oracle
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_gather_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    got = np.load(out)
+    scene = rt.build_scene(rt.SCENE_RANDOM_SPHERES)
+    p = rt.make_params(rt.scene_camera(rt.SCENE_RANDOM_SPHERES), 40, 52, 4, rng_mode=rt.RNG_COUNTER)
+    want, _ = oracle.render(scene, p)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert rtd.share_rows(rtd.split_interleaved(52, 4, 3)[2]) == list(range(16, 24)) + list(range(40, 48))
+    with pytest.raises(ValueError):
+        import torch
+        rtd.gather_rows(torch.zeros((8, 4, 3)), rtd.split_frame(8, 4, 2), 0)  # sample ranges must be summed
+
+
 @pytest.mark.parametrize("row_groups", [1, 2])
 def test_two_ranks_compose_the_frame(tmp_path, row_groups):
     import torch.multiprocessing as mp
@@ -77,10 +112,14 @@ def _gpu_worker(rank, world, port, mode, out_path):
     r.upload(scene, rt.ACCEL_LBVH)
     accum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     r.set_accumulator(accum.data_ptr(), W, H)
-    shares = rtd.split_interleaved(H, S, world) if mode == "strips" else rtd.split_frame(H, S, world)
+    shares = rtd.split_interleaved(H, S, world) if mode in ("strips", "gather") else rtd.split_frame(H, S, world)
     for frame in range(2):  # twice: the second frame's clear must not overtake the first frame's sums
         r.clear()
-        rtd.render_and_combine(r, rtd.apply_share(p, shares[rank]), accum, dst=0, bands=3)
+        if mode == "gather":
+            r.render(rtd.apply_share(p, shares[rank]))
+            rtd.gather_rows(accum, shares, rank, dst=0, after=r)
+        else:
+            rtd.render_and_combine(r, rtd.apply_share(p, shares[rank]), accum, dst=0, bands=3)
     torch.cuda.synchronize()
     if rank == 0:
         got = accum.cpu().numpy().copy()
@@ -114,6 +153,11 @@ def _rccl_single_worker(rank, world, port, out_path):
         r.clear()
         rtd.render_and_combine(r, p, accum, dst=0, bands=bands)
         frames.append(accum.clone())  # on torch's stream, which render_and_combine ordered behind the sums: no host wait
+    for _ in range(2):  # the gather of disjoint rows, through RCCL's send / receive, ordered the same way
+        r.clear()
+        r.render(p)
+        rtd.gather_rows(accum, rtd.split_interleaved(H, S, 1), 0, dst=0, after=r)
+        frames.append(accum.clone())
     torch.cuda.synchronize()
     r.set_accumulator(0, 0, 0)
     r.clear()
@@ -138,7 +182,7 @@ def test_device_ordered_sum_with_rccl_on_one_rank(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["strips", "samples"])
+@pytest.mark.parametrize("mode", ["strips", "gather", "samples"])
 def test_two_ranks_on_one_gpu_hip_path(tmp_path, mode):
     """The N > 1 flow with the HIP kernels: shares rendered band by band, each band's sum queued behind its render
     on the device.  Strips: disjoint pixels, exact.  Sample ranges: the two partial sums added once, float32 rounding."""
@@ -147,7 +191,7 @@ def test_two_ranks_on_one_gpu_hip_path(tmp_path, mode):
     mp.spawn(_gpu_worker, args=(2, _free_port(), mode, out), nprocs=2, join=True)
     got, want = np.load(out)
     assert want.mean() > 0.05
-    if mode == "strips":
+    if mode in ("strips", "gather"):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     else:
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
