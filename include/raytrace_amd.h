@@ -375,6 +375,32 @@ RT_API int rt_get_scene_info(rt_ctx* ctx, rt_scene_info* out);
  */
 RT_API int rt_get_stream(rt_ctx* ctx, void** hip_stream);
 
+/*
+ * The sum of the ranks' accumulators as a library call (no counterpart in the
+ * reference, which renders on one device): one context per GPU, one process
+ * per context, RCCL over xGMI underneath, queued on the context's own stream
+ * behind the renders it follows — no host wait, no other runtime involved.
+ *   rt_comm_unique_id   on one rank: 128 bytes (RT_COMM_ID_BYTES) that the caller
+ *                       hands to every other rank by whatever means it has
+ *   rt_comm_init        every rank, with the same id: joins the group of `world`
+ *                       ranks as `rank` on the context's device
+ *   rt_comm_reduce      every rank, after its renders: adds the accumulators of
+ *                       all ranks (same image size everywhere) onto rank `root`'s;
+ *                       the other ranks' accumulators are left as they were.
+ *                       Sample counts are not exchanged: the root calls
+ *                       rt_set_accumulated_samples if the ranks rendered
+ *                       different sample ranges.
+ *   rt_comm_destroy     leaves the group (rt_destroy does it too)
+ * RCCL is loaded when rt_comm_unique_id or rt_comm_init is first called
+ * (librccl.so.1; a process that already holds one, PyTorch's for instance,
+ * shares it); RT_ERR_DEVICE if it cannot be had.
+ */
+#define RT_COMM_ID_BYTES 128
+RT_API int rt_comm_unique_id(void* id_out);
+RT_API int rt_comm_init(rt_ctx* ctx, const void* id, int rank, int world);
+RT_API int rt_comm_reduce(rt_ctx* ctx, int root);
+RT_API int rt_comm_destroy(rt_ctx* ctx);
+
 /* Depth of the LBVH of the uploaded scene (largest number of ancestors of a
  * leaf; it sizes the traversal stack).  0 for the linear scan. */
 RT_API int rt_lbvh_depth(rt_ctx* ctx);

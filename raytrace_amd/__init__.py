@@ -295,6 +295,26 @@ class Renderer:
         self._check(self.lib.rt_get_scene_info(self.ctx, ctypes.byref(info)))
         return info.as_dict()
 
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """rt_comm_unique_id: the 128 bytes one rank makes and every rank of the group passes to comm_init."""
+        buf = ctypes.create_string_buffer(128)
+        rc = _lib.device_lib().rt_comm_unique_id(buf)
+        if rc != 0:
+            raise RtError(rc, _lib.device_lib().rt_last_error().decode())
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == 128
+        self._check(self.lib.rt_comm_init(self.ctx, unique_id, int(rank), int(world)))
+
+    def comm_reduce(self, root=0):
+        """rt_comm_reduce: the ranks' accumulators summed onto `root`'s, queued on the context's stream."""
+        self._check(self.lib.rt_comm_reduce(self.ctx, int(root)))
+
+    def comm_destroy(self):
+        self._check(self.lib.rt_comm_destroy(self.ctx))
+
     def stream(self):
         """The context's hipStream_t as an integer (wrap it with torch.cuda.ExternalStream to order torch work after it)."""
         st = ctypes.c_void_p()

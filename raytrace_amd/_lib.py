@@ -76,7 +76,7 @@ class RtCamera(ctypes.Structure):
 # Entry points every build of the device library must export (checked by tests).
 DEVICE_SYMBOLS = [
     "rt_last_error", "rt_init", "rt_destroy", "rt_gl_bind_buffer", "rt_gl_buffer_sub_data", "rt_gl_buffer_data",
-    "rt_gl_buffer_bytes", "rt_gl_reset", "rt_gl_dropped_writes", "rt_scene_upload", "rt_scene_upload_objects", "rt_render", "rt_render_counted",
+    "rt_gl_buffer_bytes", "rt_gl_reset", "rt_gl_dropped_writes", "rt_scene_upload", "rt_scene_upload_objects", "rt_comm_unique_id", "rt_comm_init", "rt_comm_reduce", "rt_comm_destroy", "rt_render", "rt_render_counted",
     "rt_clear", "rt_set_accumulator", "rt_set_accumulated_samples", "rt_readback", "rt_trace_batch",
     "rt_trace_batch_device", "rt_synchronize", "rt_get_counters", "rt_last_kernel_ms", "rt_last_build_ms",
     "rt_lbvh_depth", "rt_device_count", "rt_seed_texture", "rt_accumulator_read", "rt_accumulator_write",
@@ -155,6 +155,14 @@ def device_lib():
         lib.rt_init.argtypes = [ctypes.c_int, P(ctypes.c_void_p)]
         lib.rt_destroy.restype = None
         lib.rt_destroy.argtypes = [ctypes.c_void_p]
+        lib.rt_comm_unique_id.restype = ctypes.c_int
+        lib.rt_comm_unique_id.argtypes = [ctypes.c_void_p]
+        lib.rt_comm_init.restype = ctypes.c_int
+        lib.rt_comm_init.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        lib.rt_comm_reduce.restype = ctypes.c_int
+        lib.rt_comm_reduce.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.rt_comm_destroy.restype = ctypes.c_int
+        lib.rt_comm_destroy.argtypes = [ctypes.c_void_p]
         lib.rt_scene_upload_objects.restype = ctypes.c_int
         lib.rt_scene_upload_objects.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
                                                 ctypes.c_int, ctypes.c_int]

@@ -13,7 +13,10 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is loaded on first use (rccl_api)
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
@@ -143,6 +146,8 @@ struct rt_ctx {
   dev_buf<float> inv_r;
   dev_buf<int32_t> sph_mat, mat_type;
   dev_buf<float4> mat_a;
+  void* comm = nullptr;  // the RCCL communicator of rt_comm_init
+  int comm_rank = 0, comm_world = 0;
   int n_quads = 0;
   dev_buf<float4> quad_qd, quad_u, quad_v, quad_n, quad_w;
   dev_buf<int32_t> quad_idx, quad_of;
@@ -1318,6 +1323,7 @@ void rt_destroy(rt_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  (void)rt_comm_destroy(c);
   c->sph.release(); c->inv_r.release(); c->sph_mat.release(); c->mat_type.release(); c->mat_a.release();
   c->quad_qd.release(); c->quad_u.release(); c->quad_v.release(); c->quad_n.release(); c->quad_w.release(); c->quad_idx.release(); c->quad_of.release();
   c->big_sph.release(); c->big_idx.release(); c->tree_sph.release(); c->tree_r.release(); c->tree_orig.release();
@@ -1961,6 +1967,98 @@ int rt_get_scene_info(rt_ctx* c, rt_scene_info* out) {
   out->tree_in_lds = c->search == SEARCH_TREE_LDS_RAY || c->search == SEARCH_TREE_LDS_NODE;
   out->pad_per_ray = c->search == SEARCH_TREE_LDS_RAY || c->search == SEARCH_TREE_GLB_RAY;
   out->node_bytes = c->n_nodes > 0 ? (out->tree_in_lds ? (int)sizeof(bvh4_node) : (int)sizeof(bvh4q_node)) : 0;
+  return RT_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// RCCL's entry points, looked up at first use: a caller that never sums across ranks needs no RCCL at all, and a
+// process that already holds a copy (PyTorch ships its own) must not get a second one.
+struct rccl_api {
+  decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+  decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+  decltype(&ncclReduce) reduce = nullptr;
+  decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclGetErrorString) error_string = nullptr;
+  bool ok = false;
+};
+
+const rccl_api& rccl() {
+  static const rccl_api api = [] {
+    rccl_api a;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (h) break;
+    }
+    if (!h) return a;
+    a.get_unique_id = reinterpret_cast<decltype(a.get_unique_id)>(dlsym(h, "ncclGetUniqueId"));
+    a.comm_init_rank = reinterpret_cast<decltype(a.comm_init_rank)>(dlsym(h, "ncclCommInitRank"));
+    a.reduce = reinterpret_cast<decltype(a.reduce)>(dlsym(h, "ncclReduce"));
+    a.comm_destroy = reinterpret_cast<decltype(a.comm_destroy)>(dlsym(h, "ncclCommDestroy"));
+    a.error_string = reinterpret_cast<decltype(a.error_string)>(dlsym(h, "ncclGetErrorString"));
+    a.ok = a.get_unique_id && a.comm_init_rank && a.reduce && a.comm_destroy && a.error_string;
+    return a;
+  }();
+  return api;
+}
+
+int rccl_fail(const char* what, ncclResult_t r) { return fail(RT_ERR_DEVICE, "%s: %s", what, rccl().error_string(r)); }
+
+}  // namespace
+
+extern "C" {
+
+int rt_comm_unique_id(void* id_out) {
+  if (!id_out) return fail(RT_ERR_INVALID, "null id");
+  if (!rccl().ok) return fail(RT_ERR_DEVICE, "RCCL (librccl.so.1) cannot be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+  ncclUniqueId id;
+  const ncclResult_t r = rccl().get_unique_id(&id);
+  if (r != ncclSuccess) return rccl_fail("ncclGetUniqueId", r);
+  static_assert(sizeof(id) == RT_COMM_ID_BYTES, "the id is RT_COMM_ID_BYTES long");
+  std::memcpy(id_out, &id, sizeof(id));
+  return RT_OK;
+}
+
+int rt_comm_init(rt_ctx* c, const void* id_bytes, int rank, int world) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!id_bytes || world < 1 || rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "bad group arguments (rank %d of %d)", rank, world);
+  if (c->comm) return fail(RT_ERR_STATE, "the context is in a group already");
+  if (!rccl().ok) return fail(RT_ERR_DEVICE, "RCCL (librccl.so.1) cannot be loaded");
+  ncclUniqueId id;
+  std::memcpy(&id, id_bytes, sizeof(id));
+  ncclComm_t comm = nullptr;
+  const ncclResult_t r = rccl().comm_init_rank(&comm, world, id, rank);  // on the current device: check_ctx has set it
+  if (r != ncclSuccess) return rccl_fail("ncclCommInitRank", r);
+  c->comm = comm;
+  c->comm_rank = rank;
+  c->comm_world = world;
+  return RT_OK;
+}
+
+int rt_comm_reduce(rt_ctx* c, int root) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!c->comm) return fail(RT_ERR_STATE, "rt_comm_reduce before rt_comm_init");
+  if (root < 0 || root >= c->comm_world) return fail(RT_ERR_INVALID, "root %d out of range [0,%d)", root, c->comm_world);
+  if (!c->accum() || c->acc_w < 1) return fail(RT_ERR_STATE, "nothing rendered yet");
+  const size_t nv = 3 * (size_t)c->acc_w * (size_t)c->acc_h;
+  // in place on the root; the others only send
+  const ncclResult_t r = rccl().reduce(c->accum(), c->accum(), nv, ncclFloat32, ncclSum, root, static_cast<ncclComm_t>(c->comm), c->stream);
+  if (r != ncclSuccess) return rccl_fail("ncclReduce", r);
+  return RT_OK;
+}
+
+int rt_comm_destroy(rt_ctx* c) {
+  if (!c) return fail(RT_ERR_INVALID, "null context");
+  if (c->comm) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)rccl().comm_destroy(static_cast<ncclComm_t>(c->comm));
+    c->comm = nullptr;
+  }
   return RT_OK;
 }
 
