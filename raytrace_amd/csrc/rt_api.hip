@@ -903,22 +903,28 @@ long long blocks_for(const rt_ctx* c, int per_cu, int tw, int th, const render_a
   return blocks < 1 ? 1 : blocks;
 }
 
-template <int SEARCH, int RNG, bool COUNTED>
-hipError_t launch_render_one(rt_ctx* c, const rt_params* p, hipStream_t st, render_args a) {
+template <int SEARCH, int RNG, bool COUNTED, bool NOISE>
+hipError_t launch_render_noise(rt_ctx* c, const rt_params* p, hipStream_t st, render_args a) {
   using T = search_traits<SEARCH>;
   const int tw = p->tile_x1 - p->tile_x0, th = a.vrows;
   const size_t lds = search_lds_bytes<SEARCH>(counts_of(c));
-  hipError_t e = allow_lds(rt_render_kernel<SEARCH, RNG, COUNTED>, lds);
+  hipError_t e = allow_lds(rt_render_kernel<SEARCH, RNG, COUNTED, NOISE>, lds);
   if (e != hipSuccess) return e;
   int per_cu = 0;
-  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_kernel<SEARCH, RNG, COUNTED>, T::threads, lds);
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_kernel<SEARCH, RNG, COUNTED, NOISE>, T::threads, lds);
   if (e != hipSuccess) return e;
   if (per_cu < 1) per_cu = 1;
   const long long blocks = blocks_for<T::waves>(c, per_cu, tw, th, a);
   e = attach_overflow<SEARCH>(c, blocks, a.sc);
   if (e != hipSuccess) return e;
-  rt_render_kernel<SEARCH, RNG, COUNTED><<<dim3((unsigned)blocks), T::threads, lds, st>>>(a);
+  rt_render_kernel<SEARCH, RNG, COUNTED, NOISE><<<dim3((unsigned)blocks), T::threads, lds, st>>>(a);
   return hipGetLastError();
+}
+
+// (the kernels come in two forms, for scenes with and without the noise-textured material: see shade_hit)
+template <int SEARCH, int RNG, bool COUNTED>
+hipError_t launch_render_one(rt_ctx* c, const rt_params* p, hipStream_t st, render_args a) {
+  return c->have_noise ? launch_render_noise<SEARCH, RNG, COUNTED, true>(c, p, st, a) : launch_render_noise<SEARCH, RNG, COUNTED, false>(c, p, st, a);
 }
 
 // rt_render_stored_kernel: the search's LDS plus one camera ray in reserve per lane.
@@ -927,23 +933,28 @@ size_t stored_lds_bytes(const rt_ctx* c) {
   return pad16(search_lds_bytes<SEARCH>(counts_of(c))) + (size_t)search_traits<SEARCH>::waves * RT_RESERVE_BYTES;
 }
 
-template <int SEARCH, bool COUNTED>
-hipError_t launch_stored_one(rt_ctx* c, hipStream_t st, render_args a) {
+template <int SEARCH, bool COUNTED, bool NOISE>
+hipError_t launch_stored_noise(rt_ctx* c, hipStream_t st, render_args a) {
   using T = search_traits<SEARCH>;
   const int tw = a.p.tile_x1 - a.p.tile_x0, th = a.vrows;
   const size_t lds = stored_lds_bytes<SEARCH>(c);
   a.reserve_offset = (uint32_t)(lds - (size_t)T::waves * RT_RESERVE_BYTES);
-  hipError_t e = allow_lds(rt_render_stored_kernel<SEARCH, COUNTED>, lds);
+  hipError_t e = allow_lds(rt_render_stored_kernel<SEARCH, COUNTED, NOISE>, lds);
   if (e != hipSuccess) return e;
   int per_cu = 0;
-  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_stored_kernel<SEARCH, COUNTED>, T::threads, lds);
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_stored_kernel<SEARCH, COUNTED, NOISE>, T::threads, lds);
   if (e != hipSuccess) return e;
   if (per_cu < 1) per_cu = 1;
   const long long blocks = blocks_for<T::waves>(c, per_cu, tw, th, a);
   e = attach_overflow<SEARCH>(c, blocks, a.sc);
   if (e != hipSuccess) return e;
-  rt_render_stored_kernel<SEARCH, COUNTED><<<dim3((unsigned)blocks), T::threads, lds, st>>>(a);
+  rt_render_stored_kernel<SEARCH, COUNTED, NOISE><<<dim3((unsigned)blocks), T::threads, lds, st>>>(a);
   return hipGetLastError();
+}
+
+template <int SEARCH, bool COUNTED>
+hipError_t launch_stored_one(rt_ctx* c, hipStream_t st, render_args a) {
+  return c->have_noise ? launch_stored_noise<SEARCH, COUNTED, true>(c, st, a) : launch_stored_noise<SEARCH, COUNTED, false>(c, st, a);
 }
 
 template <int SEARCH>

@@ -325,7 +325,7 @@ RT_DEV Q take_items(bool need, Q* queue, Q& pool_next, Q& pool_end) {
 // bounce() for a lane whose search is over (fs:201-223): hit record and material scatter, or the sky.  Returns
 // whether the path goes on; if so, srch.ts.o / srch.ts.d hold the next segment's ray.  alb is the path's throughput
 // and, when the path ends, its radiance.
-template <int SEARCH, int RNG, bool COUNTED>
+template <int SEARCH, int RNG, bool COUNTED, bool NOISE>
 RT_DEV bool shade_finished(searcher<SEARCH, COUNTED>& srch, const scene_dev& sc, const scene_view& sv, uint32_t bounce_limit, f3& alb,
                            uint32_t& rng, uint32_t& count, lane_counters& k) {
   float t;
@@ -355,7 +355,7 @@ RT_DEV bool shade_finished(searcher<SEARCH, COUNTED>& srch, const scene_dev& sc,
     const int type = sv.mat_type[h.mat];
     next_o = h.point;  // fs:211-212
     count = count + 1u;
-    cont = shade_hit<RNG, COUNTED>(h, type, ma.w, mk3(ma.x, ma.y, ma.z), sc.noise, d, alb, rng, k);
+    cont = shade_hit<RNG, COUNTED, NOISE>(h, type, ma.w, mk3(ma.x, ma.y, ma.z), sc.noise, d, alb, rng, k);
   } else {  // fs:217-218
     alb = sky_radiance(d, alb);
     cont = false;
@@ -420,7 +420,7 @@ RT_DEV void camera_ray(const camera_consts& C, int x, int y, uint32_t& rng, f3& 
 // phase for the ready ones.  Rays that finish their traversal early therefore
 // do not hold the wave until the slowest ray of the segment is done; they wait
 // only until enough lanes are ready to make the path phase worth issuing.
-template <int SEARCH, int RNG, bool COUNTED>
+template <int SEARCH, int RNG, bool COUNTED, bool NOISE>
 __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARCH>::render_waves_per_simd) void rt_render_kernel(const render_args A) {
   const rt_params& P = A.p;
   const scene_dev& sc = A.sc;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
     bool start_segment = false;
     if (ready && pending) {  // the search for the current segment is over: bounce(), fs:207-219
       pending = false;
-      const bool cont = shade_finished<SEARCH, RNG, COUNTED>(srch, sc, sv, P.bounce_limit, alb, rng, count, k);
+      const bool cont = shade_finished<SEARCH, RNG, COUNTED, NOISE>(srch, sc, sv, P.bounce_limit, alb, rng, count, k);
       RT_CLK_STOP(1);
       if (cont) {
         start_segment = true;
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
 #define RT_REFILL_MIN 16
 #define RT_RESERVE_BYTES 2048  // per wave: two rows of 64 float4
 
-template <int SEARCH, bool COUNTED>
+template <int SEARCH, bool COUNTED, bool NOISE>
 __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARCH>::render_waves_per_simd) void rt_render_stored_kernel(const render_args A) {
   constexpr int RNG = RT_RNG_COUNTER;
   const rt_params& P = A.p;
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
     bool start_segment = false;
     if (ready && pending) {
       pending = false;
-      if (shade_finished<SEARCH, RNG, COUNTED>(srch, sc, sv, P.bounce_limit, alb, rng, count, k)) {
+      if (shade_finished<SEARCH, RNG, COUNTED, NOISE>(srch, sc, sv, P.bounce_limit, alb, rng, count, k)) {
         start_segment = true;
       } else {  // fs:132: the sample's radiance, and what the path cost
         A.split_samples[cur_slot] = make_float4(alb.x, alb.y, alb.z, __uint_as_float(path_segments));

@@ -14,7 +14,12 @@ import csv, json, os, sys
 def timed_step_rows(path, counter):
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    last_counted = max((i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(("void rt_render_kernel", "void rt_render_stored_kernel", "void rt_trace_kernel")) and ", true>(" in r["Kernel_Name"]), default=-1)
+    def counted(name):  # rt_render_kernel<search, rng, counted, noise>, rt_render_stored_kernel<search, counted, noise>, rt_trace_kernel<search, counted>
+        if not name.startswith(("void rt_render_kernel<", "void rt_render_stored_kernel<", "void rt_trace_kernel<")):
+            return False
+        args = [a.strip() for a in name[name.index("<") + 1:name.index(">")].split(",")]
+        return (args[-1] if name.startswith("void rt_trace_kernel<") else args[-2]) == "true"
+    last_counted = max((i for i, r in enumerate(rows) if counted(r["Kernel_Name"])), default=-1)
     return rows[last_counted + 1:]
 
 def main():
