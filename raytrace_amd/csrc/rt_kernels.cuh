@@ -666,10 +666,14 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
   searcher<SEARCH, COUNTED> srch;
   srch.ref_mask = sc.ref_mask;
   srch.reset();
-  bool alive = false, pending = false;       // a path is in flight; its finished search waits to be shaded
-  bool reserve_full = false;                 // the lane's reserve holds a camera ray
-  bool job_left = false, jobs_done = false;  // the lane's job has samples left; the queue is dry
-  bool done = P.sample_end <= P.sample_begin;
+  // The lane's state, as bits of one vector register (flags of their own would be lane masks in scalar registers, of
+  // which this kernel has none to spare, merged at every join of the wave's loop):
+  //   ALIVE a path is in flight, PENDING its finished search waits to be shaded, RESERVE the lane's reserve holds a
+  //   camera ray, JOB_LEFT the lane's job has samples left, JOBS_DONE the queue is dry, DONE the lane is through
+  enum : uint32_t { ALIVE = 1u, PENDING = 2u, RESERVE = 4u, JOB_LEFT = 8u, JOBS_DONE = 16u, DONE = 32u };
+  uint32_t st = P.sample_end <= P.sample_begin ? DONE : 0u;
+  auto has = [&](uint32_t bits) { return (st & bits) != 0u; };
+  auto none = [&](uint32_t bits) { return (st & bits) == 0u; };
   int jx = 0, jy = 0, js = 0, js_end = 0;    // the job: pixel, next sample to make a ray for, end
   uint32_t jrow = 0, jpixel = 0;             // its row in the store; its pixel index
   uint32_t rng = 0, count = 0, cur_slot = 0, path_segments = 0;
@@ -677,7 +681,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
   uint32_t pool_next = 0, pool_end = 0;
 
   while (true) {
-    const unsigned long long m_live = __ballot(!done);
+    const unsigned long long m_live = __ballot(none(DONE));
     if (m_live == 0ull) break;
     while (search_traits<SEARCH>::tree) {
       const unsigned long long m_trav = __ballot(srch.active());
@@ -696,17 +700,17 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       }
     }
     RT_COUNT(k, path_wave_phases, (threadIdx.x & 63) == 0 ? 1u : 0u);
-    const bool ready = !(srch.active() || done);
+    const bool ready = !srch.active() && none(DONE);
     RT_COUNT(k, path_lane_phases, ready ? 1u : 0u);
 
     bool start_segment = false;
-    if (ready && pending) {
-      pending = false;
+    if (ready && has(PENDING)) {
+      st &= ~PENDING;
       if (shade_finished<SEARCH, RNG, COUNTED, NOISE>(srch, sc, sv, P.bounce_limit, alb, rng, count, k)) {
         start_segment = true;
       } else {  // fs:132: the sample's radiance, and what the path cost
         A.split_samples[cur_slot] = make_float4(alb.x, alb.y, alb.z, __uint_as_float(path_segments));
-        alive = false;
+        st &= ~ALIVE;
       }
     }
     // a lane without a path takes the ray it holds in reserve
@@ -719,25 +723,24 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       alb = mk3(1.0f, 1.0f, 1.0f);
       count = 0;
       path_segments = 0;
-      alive = true;
-      reserve_full = false;
+      st = (st | ALIVE) & ~RESERVE;
       start_segment = true;
       RT_COUNT(k, paths, 1);
     };
-    if (ready && !alive && reserve_full) take_reserve();
+    if (ready && (st & (ALIVE | RESERVE)) == RESERVE) take_reserve();
     // Refill the reserves: worth a wave when `refill_vote` are empty; when a lane is out of rays, already at
     // `refill_min` empty ones (below that the lane waits for company) — or at once if no lane of the wave would
     // be traversing meanwhile.
-    const bool fill = !reserve_full && !jobs_done && !done;
+    const bool fill = none(RESERVE | JOBS_DONE | DONE);
     const unsigned long long m_fill = __ballot(fill);
     const int n_fill = __popcll(m_fill);
-    const bool starving = __ballot(fill && ready && !alive) != 0ull;
+    const bool starving = __ballot(fill && ready && none(ALIVE)) != 0ull;
     if (m_fill != 0ull && (n_fill >= A.refill_vote || (starving && (n_fill >= A.refill_min || __ballot(srch.active() || start_segment) == 0ull)))) {
-      const uint32_t item = take_items<unsigned int, RT_JOB_CHUNK>(fill && !job_left, A.queue, pool_next, pool_end);
+      const uint32_t item = take_items<unsigned int, RT_JOB_CHUNK>(fill && none(JOB_LEFT), A.queue, pool_next, pool_end);
       if (fill) {
-        if (!job_left) {
+        if (none(JOB_LEFT)) {
           if (item >= total_items) {
-            jobs_done = true;
+            st |= JOBS_DONE;
           } else {
             int vy;
             uint32_t rect_pixel;
@@ -763,29 +766,29 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
             }
             jy = real_row(vy, P.tile_y0, P.strip_count, P.strip_index);
             jpixel = (uint32_t)jy * (uint32_t)P.width + (uint32_t)jx;
-            job_left = jx < P.tile_x1 && vy < th && js < js_end;
+            if (jx < P.tile_x1 && vy < th && js < js_end) st |= JOB_LEFT;
           }
         }
-        if (job_left) {  // fs:117-131 for the job's next sample, into the reserve
+        if (has(JOB_LEFT)) {  // fs:117-131 for the job's next sample, into the reserve
           uint32_t r = counter_key(P.seed, jpixel, (uint32_t)js);
           f3 ro, rd;
           camera_ray<RNG, COUNTED>(C, jx, jy, r, ro, rd, k);
           const uint32_t slot = (uint32_t)sample_slot((uint32_t)(js - P.sample_begin), (size_t)jrow, rows);
           reserve[0] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(r));
           reserve[64] = make_float4(rd.x, rd.y, rd.z, __uint_as_float(slot));
-          reserve_full = true;
+          st |= RESERVE;
           js++;
-          job_left = js < js_end;
+          if (!(js < js_end)) st &= ~JOB_LEFT;
         }
       }
-      if (ready && !alive && reserve_full) take_reserve();
+      if (ready && (st & (ALIVE | RESERVE)) == RESERVE) take_reserve();
     }
-    if (ready && !alive && !reserve_full && jobs_done) done = true;  // no path, no reserve, no job: the lane is through
+    if (ready && (st & (ALIVE | RESERVE | JOBS_DONE)) == JOBS_DONE) st |= DONE;  // no path, no reserve, no job: the lane is through
     if (start_segment) {
       RT_COUNT(k, segments, 1);
       path_segments++;
       srch.begin(sc, sv, srch.ts.o, srch.ts.d, k);
-      pending = true;
+      st |= PENDING;
     }
   }
   flush_counters<COUNTED>(A.counters, k);
