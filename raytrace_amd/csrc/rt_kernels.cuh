@@ -439,11 +439,13 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
 
   searcher<SEARCH, COUNTED> srch;
   srch.ref_mask = sc.ref_mask;
-  bool have = false;        // this lane owns a pixel
-  bool alive = false;       // a path of that pixel is in flight
-  bool pending = false;     // a finished search waits to be shaded
+  // The lane's state, as bits of one vector register (see rt_render_stored_kernel): HAVE this lane owns a pixel, ALIVE
+  // a path of that pixel is in flight, PENDING a finished search waits to be shaded, EXHAUSTED the queue is dry.
+  enum : uint32_t { HAVE = 1u, ALIVE = 2u, PENDING = 4u, EXHAUSTED = 8u };
+  uint32_t st = P.sample_end <= P.sample_begin ? EXHAUSTED : 0u;
+  auto has = [&](uint32_t bits) { return (st & bits) != 0u; };
+  auto none = [&](uint32_t bits) { return (st & bits) == 0u; };
   srch.reset();             // (a lane is traversing while its search is active: no flag of its own)
-  bool exhausted = P.sample_end <= P.sample_begin;
   int x = 0, y = 0, s = 0, s_end = P.sample_end;
   uint32_t pixel = 0, rect_pixel = 0, rng = 0, count = 0, pixel_segments = 0, split_row = RT_JOB_WHOLE;
   f3 colour = mk3(0.0f, 0.0f, 0.0f);
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       dst[1] = colour.y;
       dst[2] = colour.z;
     }
-    have = false;
+    st &= ~HAVE;
   };
   // The finished path's radiance joins the pixel's running sum, or, for a pixel cut into
   // several jobs, goes to its own slot to be summed in order later.
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
   while (true) {
     // Traversal steps for the lanes that are traversing, until enough lanes are ready for the path phase to be worth
     // a full wave (or no lane is traversing).  Which lanes have run out of work changes in the path phase only.
-    const unsigned long long m_live = __ballot(!exhausted);
+    const unsigned long long m_live = __ballot(none(EXHAUSTED));
     if (m_live == 0ull) break;
     while (search_traits<SEARCH>::tree) {  // `pending` (set at begin) marks the result as unread
       const unsigned long long m_trav = __ballot(srch.active());
@@ -509,30 +511,30 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
     }
     RT_CLK_START();
     RT_COUNT(k, path_wave_phases, (threadIdx.x & 63) == 0 ? 1u : 0u);
-    const bool ready = !(srch.active() || exhausted);  // only ready lanes take the path phase
+    const bool ready = !srch.active() && none(EXHAUSTED);  // only ready lanes take the path phase
     RT_COUNT(k, path_lane_phases, ready ? 1u : 0u);
 
     bool start_segment = false;
-    if (ready && pending) {  // the search for the current segment is over: bounce(), fs:207-219
-      pending = false;
+    if (ready && has(PENDING)) {  // the search for the current segment is over: bounce(), fs:207-219
+      st &= ~PENDING;
       const bool cont = shade_finished<SEARCH, RNG, COUNTED, NOISE>(srch, sc, sv, P.bounce_limit, alb, rng, count, k);
       RT_CLK_STOP(1);
       if (cont) {
         start_segment = true;
       } else {  // fs:132: colour += raycast(...)
         add_sample();
-        alive = false;
+        st &= ~ALIVE;
         s++;
         if (s >= s_end) close_pixel();
       }
     }
     RT_CLK_STOP(3);
-    const bool need_pixel = ready && !start_segment && !have;
+    const bool need_pixel = ready && !start_segment && none(HAVE);
     const uint32_t item = take_items<unsigned int, RT_JOB_CHUNK>(need_pixel, A.queue, pool_next, pool_end);
     if (ready && !start_segment) {
-      if (!have) {  // the next pixel
+      if (none(HAVE)) {  // the next pixel
         if (item >= total_items) {
-          exhausted = true;
+          st |= EXHAUSTED;
         } else {
           uint4 job = make_uint4(0u, (uint32_t)P.sample_begin, (uint32_t)P.sample_end, RT_JOB_WHOLE);
           int vy;
@@ -558,12 +560,11 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
           }
           y = real_row(vy, P.tile_y0, P.strip_count, P.strip_index);
           if (x < P.tile_x1 && vy < th) {
-            have = true;
+            st = (st | HAVE) & ~ALIVE;
             pixel = (uint32_t)y * (uint32_t)P.width + (uint32_t)x;
             s = (int)job.y;
             s_end = (int)job.z;
             split_row = A.pass == 3 ? rect_pixel : job.w;
-            alive = false;
             pixel_segments = 0;
             if (A.pass == 2) {  // continue the sum and the RNG stream the probe pass left
               const float* src = A.carry_colour + 3 * (size_t)rect_pixel;
@@ -585,19 +586,19 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
         }
       }
       RT_CLK_STOP(3);
-      if (have && !alive) {  // fs:117-131: next camera sample of this pixel
+      if ((st & (HAVE | ALIVE)) == HAVE) {  // fs:117-131: next camera sample of this pixel
         if (RNG == RT_RNG_COUNTER) rng = counter_key(P.seed, pixel, (uint32_t)s);
         f3 ro, rdir;
         camera_ray<RNG, COUNTED>(C, x, y, rng, ro, rdir, k);
         alb = mk3(1.0f, 1.0f, 1.0f);
         count = 0;
-        alive = true;
+        st |= ALIVE;
         RT_COUNT(k, paths, 1);
         if (P.bounce_limit == 0u) {  // fs:203-205 on the first bounce()
           alb = mk3(0.0f, 0.0f, 0.0f);
           RT_COUNT(k, limit_hits, 1);
           add_sample();
-          alive = false;
+          st &= ~ALIVE;
           s++;
           if (s >= s_end) close_pixel();
         } else {
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       RT_COUNT(k, segments, 1);
       pixel_segments++;
       srch.begin(sc, sv, srch.ts.o, srch.ts.d, k);
-      pending = true;
+      st |= PENDING;
     }
     RT_CLK_STOP(5);
   }
