@@ -85,7 +85,7 @@ constexpr size_t kProbeBudgetBytes = (size_t)4 << 30;
 // group of four neighbouring rows, where three separate words per sample were written as partial lines (measured:
 // 3.1 bytes written per byte of payload).
 constexpr size_t kSampleFloats = 4;
-inline size_t stored_samples(int n) { return (size_t)n; }
+inline size_t stored_samples(int n) { return ((size_t)n + 1) & ~(size_t)1; }  // (whole pairs of records: pair_slot)
 // Largest dynamic LDS a launch may ask for (the CU has 160 KiB).
 constexpr size_t kMaxLdsBytes = 160 * 1024;
 // The linear scan stages its sphere records in LDS up to this many bytes.
@@ -1113,6 +1113,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   // bounce limit of zero has no rays to trace; the reserves must fit LDS beside the scene).
   const bool stored_ok = p->rng_mode == RT_RNG_COUNTER && p->bounce_limit > 0u && stored_fits(c) && stored_kernel_enabled();
   a.reserve_offset = 0;
+  a.pairs = 0;
   a.refill_vote = refill_vote();
   a.refill_min = refill_min();
   a.pass = 0;
@@ -1240,6 +1241,13 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       const int splittable = max_split > 0 ? 1 : 0;
       // every pixel has a row in the store: the main pass too runs in the kernel with rays in reserve
       const int all_rows = splittable && max_split >= n && stored_ok ? 1 : 0;
+      // ... whose records go out in pairs, as long as the store stays below 2^31 records (a slot number's top bit
+      // marks the record that waits); RT_SAMPLE_PAIRS=0: every record on its own (comparison)
+      static const bool pairs_enabled = [] {
+        const char* e = getenv("RT_SAMPLE_PAIRS");
+        return !(e && e[0] == '0');
+      }();
+      const int pairs = all_rows && pairs_enabled && (unsigned long long)n * (unsigned long long)main_samples < (1ull << 31) ? 1 : 0;
       HIP_TRY(c->plan_parts.resize(n));
       HIP_TRY(c->plan_first.resize(n));
       HIP_TRY(c->plan_counts.resize(1));
@@ -1257,7 +1265,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       HIP_TRY(rocprim::exclusive_scan(c->scan_temp.p, scan_bytes, c->plan_parts.p, c->plan_first.p, 0u, n, rocprim::plus<uint32_t>(),
                                       c->stream));
       rt_plan_jobs_kernel<<<grid, 256, 0, c->stream>>>(c->order_idx.p, c->plan_parts.p, c->plan_first.p, n, main_begin,
-                                                      p->sample_end, all_rows, c->plan_jobs.p, c->plan_counts.p);
+                                                      p->sample_end, all_rows, pairs, c->plan_jobs.p, c->plan_counts.p);
       HIP_TRY(hipGetLastError());
       render_args mainp = probe;
       mainp.pass = 2;
@@ -1268,12 +1276,13 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       mainp.split_samples = reinterpret_cast<float4*>(c->split_samples.p);
       mainp.main_samples = main_samples;
       mainp.split_rows = n < max_split ? n : max_split;
+      mainp.pairs = pairs;
       e = all_rows ? launch_stored_pass(mainp) : launch(mainp, p);
       if (e == hipSuccess && splittable) {
         const uint32_t cand = n < max_split ? n : max_split;
         rt_sum_split_kernel<<<(cand + 255) / 256, 256, 0, c->stream>>>(c->order_idx.p, c->plan_parts.p, cand, c->carry_colour.p,
                                                                       reinterpret_cast<const float4*>(c->split_samples.p), main_samples, cand, p->tile_x0, p->tile_y0,
-                                                                      tw, p->width, p->strip_count, p->strip_index, all_rows, c->accum());
+                                                                      tw, p->width, p->strip_count, p->strip_index, all_rows, pairs, c->accum());
         e = hipGetLastError();
       }
     }

@@ -75,7 +75,7 @@ def test_c2_frame_in_two_halves_and_four_tiles(renderer):
                 q.tile_x0, q.tile_x1, q.tile_y0, q.tile_y1 = x0, x1, y0, y1
                 renderer.render(q)
     parts, _ = renderer.readback(rgb8=False)
-    assert (parts.view(np.uint32) == whole.view(np.uint32)).all()
+    assert same_f32(parts, whole)   # (one pixel of this frame is NaN: its payload differs between kernel variants)
 
 
 def test_c3_perlin_frame_tree_equals_scan(renderer):
