@@ -15,9 +15,9 @@ cam = rt.scene_camera(rt.SCENE_RANDOM_SPHERES)
 r.upload(scene, rt.ACCEL_LBVH)
 w, h, spp = 1920, 1080, 256
 base = None
-for n in (1, 2, 4, 8):
+for n in ([int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]):
     for rank in sorted({0, n - 1}):
-        for bands in (1, 2, 4):   # rows rendered in bands, as render_and_combine does to overlap the sums
+        for bands in ((1,) if len(sys.argv) > 1 else (1, 2, 4)):   # rows rendered in bands, as render_and_combine does to overlap the sums
             p = rtd.apply_share(rt.make_params(cam, w, h, spp), rtd.split_interleaved(h, spp, n)[rank])
             best = 1e9
             for i in range(4):
@@ -30,7 +30,7 @@ for n in (1, 2, 4, 8):
                 r.synchronize()
                 if i:
                     best = min(best, time.perf_counter() - t0)
-            if n == 1 and bands == 1:
-                base = best
+            if base is None:
+                base = best * n
             print(f"N={n} rank {rank} bands {bands}: {best * 1e3:7.2f} ms  ideal {base * 1e3 / n:7.2f} ms  efficiency {base / n / best:5.3f}", flush=True)
 r.close()
