@@ -257,7 +257,8 @@ int build_lbvh(rt_ctx* c) {
   HIP_TRY(c->leaf_sph.resize((size_t)n));
   HIP_TRY(c->leaf_r.resize((size_t)n));
   HIP_TRY(c->leaf_idx.resize((size_t)n));
-  HIP_TRY(c->nodes.resize((size_t)(n > 1 ? n - 1 : 1)));
+  const size_t max_nodes = n > 1 ? (size_t)(n - 1) : 1;  // (a 4-wide node is made from at least one binary node)
+  HIP_TRY(c->nodes.resize(max_nodes));
 
   lbvh_scratch& w = c->build;
   dev_buf<uint32_t>&bounds = w.bounds, &codes = w.codes, &codes_sorted = w.codes_sorted, &index = w.index, &index_sorted = w.index_sorted;
@@ -288,8 +289,8 @@ int build_lbvh(rt_ctx* c) {
   BUILD_TRY(child1.resize(ni));
   BUILD_TRY(node_parent.resize(ni));
   BUILD_TRY(leaf_parent.resize(nn));
-  BUILD_TRY(scalars.resize(2));  // [0] max depth, [1] 4-wide node counter
-  BUILD_TRY(slot_of.resize(ni));
+  BUILD_TRY(scalars.resize(2));  // [0] max depth of the binary tree, [1] 4-wide node counter
+  BUILD_TRY(slot_of.resize(max_nodes));  // the binary node each 4-wide node is made from
   BUILD_TRY(arrivals.resize(ni));
   BUILD_TRY(node_box.resize(6 * ni));
   BUILD_TRY(node_rmin.resize(ni));
@@ -301,13 +302,14 @@ int build_lbvh(rt_ctx* c) {
   hipStream_t st = c->stream;
   const unsigned blocks_n = (unsigned)((nn + 255) / 256);
   const unsigned blocks_i = (unsigned)((ni + 255) / 256);
-  const int one = 1;
+  const int first_free = 1;  // the root keeps slot 0
+  int wide_levels = 0;
   BUILD_TRY(hipEventRecord(c->ev_b0, st));
   BUILD_TRY(hipMemsetAsync(bounds.p, 0xFF, 3 * sizeof(uint32_t), st));
   BUILD_TRY(hipMemsetAsync(bounds.p + 3, 0x00, 3 * sizeof(uint32_t), st));
   BUILD_TRY(hipMemsetAsync(arrivals.p, 0, ni * sizeof(unsigned int), st));
   BUILD_TRY(hipMemsetAsync(scalars.p, 0, sizeof(int), st));
-  BUILD_TRY(hipMemcpyAsync(scalars.p + 1, &one, sizeof(int), hipMemcpyHostToDevice, st));
+  BUILD_TRY(hipMemcpyAsync(scalars.p + 1, &first_free, sizeof(int), hipMemcpyHostToDevice, st));
   BUILD_TRY(hipMemsetAsync(leaf_parent.p, 0xFF, nn * sizeof(int), st));  // -1: a lone leaf has no parent
   lbvh_bounds_kernel<<<blocks_n < 1024u ? blocks_n : 1024u, 256, 0, st>>>(c->tree_sph.p, n, bounds.p);
   lbvh_morton_kernel<<<blocks_n, 256, 0, st>>>(c->tree_sph.p, n, bounds.p, codes.p, index.p);
@@ -318,9 +320,24 @@ int build_lbvh(rt_ctx* c) {
     lbvh_hierarchy_kernel<<<blocks_i, 256, 0, st>>>(codes_sorted.p, n, child0.p, child1.p, node_parent.p, leaf_parent.p);
     lbvh_fit_kernel<<<blocks_n, 256, 0, st>>>(c->leaf_sph.p, c->leaf_r.p, n, child0.p, child1.p, node_parent.p,
                                               leaf_parent.p, node_box.p, node_rmin.p, arrivals.p, scalars.p);
-    lbvh_mark_kernel<<<blocks_i, 256, 0, st>>>(n - 1, node_parent.p, slot_of.p, scalars.p + 1);
-    lbvh_collapse_kernel<<<blocks_i, 256, 0, st>>>(c->leaf_sph.p, c->leaf_r.p, n - 1, child0.p, child1.p, node_box.p,
-                                                   node_rmin.p, slot_of.p, c->nodes.p);
+    // the 4-wide tree, a level per launch: level L is the slots the launches before it handed out
+    BUILD_TRY(hipMemsetAsync(slot_of.p, 0, sizeof(int), st));  // the root is made from binary node 0
+    int begin = 0, end = 1;
+    while (begin < end) {
+      lbvh_collapse_level_kernel<<<(unsigned)((end - begin + 255) / 256), 256, 0, st>>>(
+          c->leaf_sph.p, c->leaf_r.p, child0.p, child1.p, node_box.p, node_rmin.p, n - 1, slot_of.p, begin, end, scalars.p + 1,
+          c->nodes.p);
+      int handed_out = 0;
+      BUILD_TRY(hipMemcpyAsync(&handed_out, scalars.p + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+      BUILD_TRY(hipStreamSynchronize(st));
+      if (handed_out < end || (size_t)handed_out > max_nodes) {
+        cleanup();
+        return fail(RT_ERR_DEVICE, "hierarchy build: %d node slots handed out of %zu", handed_out, max_nodes);
+      }
+      begin = end;
+      end = handed_out;
+      wide_levels++;
+    }
   }
   BUILD_TRY(hipGetLastError());
   BUILD_TRY(hipEventRecord(c->ev_b1, st));
@@ -342,7 +359,7 @@ int build_lbvh(rt_ctx* c) {
     rb[0] = only.x - r; rb[1] = only.y - r; rb[2] = only.z - r;
     rb[3] = only.x + r; rb[4] = only.y + r; rb[5] = only.z + r;
   }
-  c->depth = sc[0];
+  c->depth = 2 * wide_levels;  // (attach_overflow and rt_lbvh_depth count binary levels, two to a 4-wide one)
   c->n_nodes = n > 1 ? sc[1] : 0;
   c->abs_max = 0.0f;
   for (int a = 0; a < 3; a++) {

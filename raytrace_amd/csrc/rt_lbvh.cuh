@@ -1,7 +1,7 @@
 // rt_lbvh.cuh — GPU construction of the linear bounding volume hierarchy:
 // scene bounds -> 30-bit Morton codes of the sphere centres -> radix sort ->
-// Karras-style radix tree over the sorted codes -> bottom-up box fit -> collapse
-// of every two levels into 128-byte 4-wide traversal nodes.
+// Karras-style radix tree over the sorted codes -> bottom-up box fit -> top-down
+// collapse into 128-byte 4-wide traversal nodes (largest child opened first).
 // The reference has no counterpart (it scans every sphere,
 // testFragment.fs:176-184); the hierarchy is checked against that scan.
 #pragma once
@@ -206,46 +206,75 @@ __global__ __launch_bounds__(256) void lbvh_fit_kernel(const float4* leaf_sph, c
 }
 
 // ---- collapse to a 4-wide tree ----------------------------------------------
-// Binary nodes at even depth become 4-wide nodes whose children are their
-// grandchildren (or children, where a child is a leaf).
-
-// slot_of[i] = index of the 4-wide node made from binary node i, or -1.
-// counter starts at 1: the root keeps slot 0.
-__global__ __launch_bounds__(256) void lbvh_mark_kernel(int n_internal, const int* node_parent, int* slot_of, int* counter) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_internal) return;
-  int depth = 0;
-  for (int p = node_parent[i]; p >= 0; p = node_parent[p]) depth++;
-  int slot = -1;
-  if ((depth & 1) == 0) slot = (i == 0) ? 0 : atomicAdd(counter, 1);
-  slot_of[i] = slot;
+// Top down, one launch per level of the 4-wide tree.  A 4-wide node starts from the two children of its binary node
+// and, while it has fewer than four, replaces the internal child with the largest surface area by that child's two
+// children: the boxes a ray is most likely to enter are opened at once, and nearly every node ends up with four
+// children.  The 4-wide nodes made from a node's internal children get consecutive slots (one atomic per node), so
+// that siblings — a ray that visits one often visits the next — share 128-byte lines, and the slots of a level
+// are one range [begin, end): the host reads the counter after each launch and launches the next level over what was
+// added.  (Blocks padded to even lengths, so that no pair of siblings straddles two lines, measured the same rate.)
+//
+// bin_of_slot[s] = the binary node that 4-wide node s is made from.
+__device__ __forceinline__ float box_area(const float* b) {
+  const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+  return dx * dy + dy * dz + dz * dx;
 }
 
-__global__ __launch_bounds__(256) void lbvh_collapse_kernel(const float4* leaf_sph, const float* leaf_r, int n_internal,
-                                                            const int* child0, const int* child1, const float* node_box,
-                                                            const float* node_rmin, const int* slot_of, bvh4_node* nodes) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_internal) return;
-  const int slot = slot_of[i];
-  if (slot < 0) return;
-  int kids[4];
-  int nk = 0;
-#pragma unroll
-  for (int side = 0; side < 2; side++) {
-    const int c = side == 0 ? child0[i] : child1[i];
-    if (c < 0) {
-      kids[nk++] = c;
-    } else {  // odd-depth binary node: pass its children up
-      kids[nk++] = child0[c];
-      kids[nk++] = child1[c];
-    }
-  }
+__device__ __forceinline__ bvh4_node empty_wide_node() {
   bvh4_node nd;
 #pragma unroll
-  for (int s = 0; s < 4; s++) {
+  for (int s = 0; s < 4; s++) {  // an inverted box no ray enters (tree_search::step_node), and a reference no test accepts
+    nd.lox[s] = nd.loy[s] = nd.loz[s] = __builtin_inff();
+    nd.hix[s] = nd.hiy[s] = nd.hiz[s] = -__builtin_inff();
     nd.rmin[s] = 0.0f;
+    nd.ref[s] = RT_REF_EMPTY;
+  }
+  return nd;
+}
+
+__global__ __launch_bounds__(256) void lbvh_collapse_level_kernel(const float4* leaf_sph, const float* leaf_r, const int* child0,
+                                                                  const int* child1, const float* node_box, const float* node_rmin,
+                                                                  int n_internal, int* bin_of_slot, int begin, int end, int* counter,
+                                                                  bvh4_node* nodes) {
+  const int slot = begin + (int)(blockIdx.x * 256 + threadIdx.x);
+  if (slot >= end) return;
+  const int i = bin_of_slot[slot];
+  if (i < 0 || i >= n_internal) return;  // (never: the slots of a level were all filled by the level before)
+  int k0 = child0[i], k1 = child1[i], k2 = 0, k3 = 0;
+  int nk = 2;
+  while (nk < 4) {
+    int best = -1;
+    float best_area = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      const int c = s == 0 ? k0 : s == 1 ? k1 : k2;
+      if (s < nk && c >= 0) {
+        const float area = box_area(node_box + 6 * (size_t)c);
+        if (best < 0 || area > best_area) {
+          best = s;
+          best_area = area;
+        }
+      }
+    }
+    if (best < 0) break;  // leaves only
+    const int c = best == 0 ? k0 : best == 1 ? k1 : k2;
+    const int a = child0[c], b = child1[c];
+    if (best == 0) k0 = a; else if (best == 1) k1 = a; else k2 = a;
+    if (nk == 2) k2 = b; else k3 = b;
+    nk++;
+  }
+  int m = 0;
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int c = s == 0 ? k0 : s == 1 ? k1 : s == 2 ? k2 : k3;
+    if (s < nk && c >= 0) m++;
+  }
+  int next = m > 0 ? atomicAdd(counter, m) : 0;
+  bvh4_node nd = empty_wide_node();
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    const int c = s == 0 ? k0 : s == 1 ? k1 : s == 2 ? k2 : k3;
     if (s < nk) {
-      const int c = kids[s];
       box3 b;
       if (c < 0) {
         b = sphere_box(leaf_sph, leaf_r, ~c);
@@ -258,14 +287,11 @@ __global__ __launch_bounds__(256) void lbvh_collapse_kernel(const float4* leaf_s
           b.lo[a] = node_box[6 * (size_t)c + a];
           b.hi[a] = node_box[6 * (size_t)c + 3 + a];
         }
-        nd.ref[s] = slot_of[c];
+        bin_of_slot[next] = c;
+        nd.ref[s] = next++;
       }
       nd.lox[s] = b.lo[0]; nd.loy[s] = b.lo[1]; nd.loz[s] = b.lo[2];
       nd.hix[s] = b.hi[0]; nd.hiy[s] = b.hi[1]; nd.hiz[s] = b.hi[2];
-    } else {  // unused slot: an inverted box no ray enters (tree_search::step_node), and a reference no test accepts
-      nd.lox[s] = nd.loy[s] = nd.loz[s] = __builtin_inff();
-      nd.hix[s] = nd.hiy[s] = nd.hiz[s] = -__builtin_inff();
-      nd.ref[s] = RT_REF_EMPTY;
     }
   }
   nodes[slot] = nd;
