@@ -274,6 +274,10 @@ def test_render_with_a_tree_too_big_for_lds(renderer, scale, lookfrom_z):
         if accel == rt.ACCEL_LBVH:
             c = renderer.counters()
             assert c["node_tests"] > 0 and renderer.lbvh_depth() > 8
+            # the device build opens the largest child until a node has four: nearly full nodes, a third to a half as many as leaves
+            info = renderer.scene_info()
+            assert 20000 // 3 <= info["n_nodes"] <= 11000, info
+            assert renderer.lbvh_depth() <= 2 * 20, renderer.lbvh_depth()
             want = "rt_render_kernel<lbvh4,hbm,pad_ray>" if scale < 1.0 else "rt_render_kernel<lbvh4,hbm,pad_node>"
             assert renderer.last_kernel_ms()[1] == want
             assert c["hits"] > (1000 if scale < 1.0 else 20)
