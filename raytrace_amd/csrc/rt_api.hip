@@ -761,11 +761,14 @@ int probe_sweeps() {
 }
 
 // How finely the main pass of two-pass rendering cuts expensive pixels: no job should exceed
-// 1/fineness of what a lane does on average (RT_SPLIT_FINENESS overrides, for tuning).
+// 1/fineness of what a lane does on average (RT_SPLIT_FINENESS overrides, for tuning).  A 1920x1080 frame, whose
+// every pixel is cut into six parts anyway (min_parts), runs the same from 16 to 128; frames with fewer pixels per lane
+// balance better with finer jobs: 960x540 +4 %, an eighth of the 1080p frame (one rank's strips of eight) +3 %, and
+// 3840x2160x4096 +1 % at 64 against 16.
 int split_fineness() {
   static int v = [] {
     const char* e = getenv("RT_SPLIT_FINENESS");
-    int x = e ? atoi(e) : 16;
+    int x = e ? atoi(e) : 64;
     return x < 1 ? 1 : (x > 256 ? 256 : x);
   }();
   return v;
