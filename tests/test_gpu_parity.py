@@ -368,3 +368,60 @@ def test_host_and_device_hierarchy_builds_agree(renderer, monkeypatch):
         assert_same_f32(got[1], want[1], f"t ({builder})")
         assert_same_f32(got[2], want[2], f"normal ({builder})")
     assert (want[0] >= 0).sum() > 2000
+
+
+def _scene_of(centres, radii, materials):
+    rec = np.zeros((len(radii), 32), dtype=np.uint8)
+    rec[:, 4:8] = np.ascontiguousarray(radii, dtype=np.float32).view(np.uint8).reshape(-1, 4)
+    rec[:, 16:28] = np.ascontiguousarray(centres, dtype=np.float32).view(np.uint8).reshape(-1, 12)
+    return rt.Scene(rec.tobytes(), materials)
+
+
+def test_device_build_on_degenerate_clouds(renderer, monkeypatch):
+    """The device build's top-down collapse on trees that are anything but balanced: a few spheres only (nodes with
+    fewer than four children), and 24 000 spheres of which thousands are one sphere, thousands share a Morton cell
+    and thousands lie on a line with growing gaps (chains of nodes with one internal child each).  Every ray must get
+    the scan's answer bit for bit."""
+    materials = rt.build_scene(rt.SCENE_DEFAULT).materials
+    rng = np.random.default_rng(99)
+    monkeypatch.setenv("RT_BUILDER", "lbvh")
+    for n in (2, 3, 4, 5, 9, 17):
+        centres = rng.uniform(-2, 2, (n, 3)).astype(np.float32)
+        radii = rng.uniform(0.2, 0.8, n).astype(np.float32)
+        scene = _scene_of(centres, radii, materials)
+        o = rng.uniform(-4, 4, (2048, 3)).astype(np.float32)
+        d = (centres[rng.integers(0, n, 2048)] + rng.normal(scale=0.4, size=(2048, 3)) - o).astype(np.float32)
+        renderer.upload(scene, rt.ACCEL_LBVH)
+        assert renderer.scene_info()["builder"] == "device_lbvh"
+        got = renderer.trace(o, d)
+        want = oracle.trace(scene, o, d, threads=4)
+        assert np.array_equal(got[0], want[0]), n
+        assert_same_f32(got[1], want[1], f"t ({n} spheres)")
+        assert (want[0] >= 0).sum() > 500
+    monkeypatch.delenv("RT_BUILDER")
+
+    same = np.tile(np.array([[1.0, 1.0, 1.0]], np.float32), (6000, 1))
+    cell = (np.array([[-3.0, 2.0, 0.5]]) + rng.uniform(0, 1e-3, (6000, 3))).astype(np.float32)
+    line = np.stack([1.0015 ** np.arange(6000) - 1.0, np.full(6000, -2.0), np.zeros(6000)], axis=1).astype(np.float32)
+    spread = rng.uniform(-6, 6, (6000, 3)).astype(np.float32)
+    centres = np.concatenate([same, cell, line, spread])
+    radii = np.concatenate([np.full(6000, 0.3), rng.uniform(1e-4, 0.2, 6000), np.full(6000, 0.05),
+                            rng.uniform(0.05, 0.3, 6000)]).astype(np.float32)
+    scene = _scene_of(centres, radii, materials)
+    n_rays = 16384
+    o = rng.uniform(-8, 8, (n_rays, 3)).astype(np.float32)
+    aim = centres[rng.integers(0, 18000, n_rays)] + rng.normal(scale=0.05, size=(n_rays, 3))
+    d = ((aim - o) * rng.uniform(0.5, 2.0, (n_rays, 1))).astype(np.float32)
+    renderer.upload(scene, rt.ACCEL_LINEAR)
+    want = renderer.trace(o, d)
+    renderer.upload(scene, rt.ACCEL_LBVH)
+    info = renderer.scene_info()
+    assert info["builder"] == "device_lbvh" and not info["tree_in_lds"], info
+    got = renderer.trace(o, d)
+    assert np.array_equal(got[0], want[0]), f"{(got[0] != want[0]).sum()} hit ids differ"
+    assert_same_f32(got[1], want[1], "t")
+    assert_same_f32(got[2], want[2], "normal")
+    assert (want[0] >= 0).sum() > n_rays // 4
+    ref = oracle.trace(scene, o[:1024], d[:1024], threads=8)
+    assert np.array_equal(got[0][:1024], ref[0])
+    assert_same_f32(got[1][:1024], ref[1], "t vs CPU restatement")
