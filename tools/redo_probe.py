@@ -1,3 +1,5 @@
+"""Rays a tree search hands to the scan, per million segments of a 16-spp C2 frame.  Needs a library built with
+-DRT_TUNE_COUNT_REDO=1 (RAYTRACE_AMD_LIB=...): that build counts them in the noise material's counter."""
 import sys; sys.path.insert(0,'/root/repo')
 import raytrace_amd as rt
 scene = rt.build_scene(rt.SCENE_RANDOM_SPHERES); cam = rt.scene_camera(rt.SCENE_RANDOM_SPHERES)
