@@ -230,7 +230,7 @@ def main():
                             "spheres": n_sph, "rays": n_rays_total, "lbvh_depth": r.lbvh_depth(), "ranks": world,
                             "parallelism": f"ray index ranges x{world}"}
         result["_scaling"] = "strong"  # the batch is fixed; ranks take index ranges of it
-        if accel == rt.ACCEL_LBVH:
+        if accel == rt.ACCEL_LBVH and info["builder"] != "none":
             result["build_ms"] = r.last_build_ms()
     else:
         scene = rt.build_scene(sid)
@@ -281,7 +281,9 @@ def main():
         algo_bytes = None
         info = r.scene_info()
         result["config"] = {"workload": f"{cfg['workload'].split(' ')[0]} scene {w}x{h}x{spp}spp depth50" if (args.width or args.height or args.spp) else cfg["workload"],
-                            "accel": args.accel, "builder": info["builder"], "tree_nodes": info["n_nodes"], "tree_in_lds": bool(info["tree_in_lds"]),
+                            # (the library scans scenes of up to 16 spheres even when a tree is asked for: the scan is faster there)
+                            "accel": args.accel if info["builder"] != "none" or accel != rt.ACCEL_LBVH else "lbvh asked for, linear scan taken (few spheres)",
+                            "builder": info["builder"], "tree_nodes": info["n_nodes"], "tree_in_lds": bool(info["tree_in_lds"]),
                             "spheres": scene.n_spheres, "rng": cfg["rng"],
                             "lbvh_depth": r.lbvh_depth(), "global_samples_per_pixel": total_spp,
                             "ranks": world, "collective": (None if world == 1 else f"{args.backend} gather of each rank's rows onto rank 0" if strips_only else
@@ -290,7 +292,7 @@ def main():
                                             f"row bands x sample ranges over {world} ranks" if cfg.get("strong") else
                                             f"{world} interleaved sets of 8-row strips" if strong else f"sample ranges x{world}")}
         result["_scaling"] = "strong" if strong else "weak"
-        if accel == rt.ACCEL_LBVH:
+        if accel == rt.ACCEL_LBVH and info["builder"] != "none":
             result["build_ms"] = r.last_build_ms()
 
     for _ in range(args.warmup):

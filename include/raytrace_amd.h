@@ -184,8 +184,11 @@ RT_API uint64_t rt_gl_dropped_writes(void);
  * sphere = int mat @0, float radius @4, vec3 origin @16, sphere.h:22-35;
  * material = int id @0, int type @4, float param1 @8, vec3 albedo @16,
  * material.h:29-46), flattens them to structure-of-arrays device buffers and,
- * for RT_ACCEL_LBVH, builds the hierarchy on the GPU.  The input is copied;
- * the caller keeps ownership.  There is no 64-object limit.
+ * for RT_ACCEL_LBVH, builds the hierarchy (on the host for a few thousand
+ * spheres, on the GPU beyond).  A scene of at most 16 spheres gets no
+ * hierarchy whatever `accel` says: the scan is the faster search there, with
+ * the same answers (rt_get_scene_info then reports builder RT_BUILDER_NONE).
+ * The input is copied; the caller keeps ownership.  There is no 64-object limit.
  * Fails with RT_ERR_INVALID if a sphere names a material slot >= n_materials.
  */
 RT_API int rt_scene_upload(rt_ctx* ctx, const void* spheres_std140, int n_spheres,

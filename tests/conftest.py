@@ -26,3 +26,12 @@ def renderer():
     r = rt.Renderer(0)
     yield r
     r.close()
+
+
+@pytest.fixture(autouse=True)
+def trees_for_small_scenes_too(monkeypatch):
+    """The library scans scenes of up to 16 spheres even when a tree is asked for (the scan is faster there).  The
+    tests ask for trees on the 6-sphere default scene and on scenes of two or three spheres precisely to exercise the
+    tree kernels on nodes with few children, so they lift that rule; test_small_scenes_are_scanned checks the rule
+    itself."""
+    monkeypatch.setenv("RT_SCAN_UP_TO", "0")

@@ -425,3 +425,40 @@ def test_device_build_on_degenerate_clouds(renderer, monkeypatch):
     ref = oracle.trace(scene, o[:1024], d[:1024], threads=8)
     assert np.array_equal(got[0][:1024], ref[0])
     assert_same_f32(got[1][:1024], ref[1], "t vs CPU restatement")
+
+
+def test_small_scenes_are_scanned(renderer, monkeypatch):
+    """Up to 16 spheres the scan is faster than any tree, so an upload that asks for a tree gets the scan (no tree is
+    built); the frame and a closest-hit batch are those of the tree, bit for bit."""
+    scene = rt.build_scene(rt.SCENE_DEFAULT)
+    cam = rt.scene_camera(rt.SCENE_DEFAULT)
+    p = rt.make_params(cam, 160, 90, 8, rng_mode=rt.RNG_XORSHIFT_REF)
+    o, d = rays_for(rt.SCENE_DEFAULT, 2048, 77)
+    out = {}
+    for limit in (None, "0"):
+        if limit is None:
+            monkeypatch.delenv("RT_SCAN_UP_TO")
+        else:
+            monkeypatch.setenv("RT_SCAN_UP_TO", limit)
+        renderer.upload(scene, rt.ACCEL_LBVH)
+        info = renderer.scene_info()
+        renderer.clear()
+        renderer.render(p)
+        kernel = renderer.last_kernel_ms()[1]
+        out[limit] = (renderer.readback(rgb8=False)[0], renderer.trace(o, d))
+        if limit is None:
+            assert kernel == "rt_render_kernel<linear,lds>" and info["builder"] == "none" and info["n_nodes"] == 0, (kernel, info)
+        else:
+            assert kernel == "rt_render_kernel<lbvh4,lds,pad_ray>" and info["n_nodes"] > 0, (kernel, info)
+    assert_same_f32(out[None][0], out["0"][0], "scan chosen for size vs tree")
+    assert np.array_equal(out[None][1][0], out["0"][1][0])
+    assert_same_f32(out[None][1][1], out["0"][1][1], "t")
+    acc, _ = oracle.render(scene, p)
+    assert_same_f32(out[None][0], oracle.resolve(acc, 8)[0], "scan chosen for size vs CPU restatement")
+    # 17 spheres: the tree stays
+    big = rt.build_scene(rt.SCENE_RANDOM_SPHERES)
+    monkeypatch.delenv("RT_SCAN_UP_TO")
+    renderer.upload(rt.Scene(big.spheres[:17 * 32], big.materials), rt.ACCEL_LBVH)
+    assert renderer.scene_info()["n_nodes"] > 0
+    renderer.upload(rt.Scene(big.spheres[:16 * 32], big.materials), rt.ACCEL_LBVH)
+    assert renderer.scene_info()["n_nodes"] == 0
