@@ -846,16 +846,11 @@ struct tree_search {
   }
 
   RT_DEV void finish(const scene_dev& sc, const scene_view& sv, float& t_out, int& i_out, lane_counters& k) {
-#ifndef RT_TUNE_NO_REDO  // (tuning builds: what the fallback's presence costs; without it such rays count as misses)
     if (c.redo()) {
-#ifdef RT_TUNE_COUNT_REDO  // (tuning builds: how many rays go to the scan, in the counter of the noise material)
-      RT_COUNT(k, perlin, 1);
-#endif
       hit_linear_lean<COUNTED>(sv.scan_sph, sc.n_spheres, o, d, t_out, i_out, k);
       if (QUADS) hit_quads_linear(sc, o, d, t_out, i_out);
       return;
     }
-#endif
     t_out = c.best_i >= 0 ? c.best_t : -1.0f;
     i_out = c.best_i;
   }
