@@ -36,13 +36,37 @@ RT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 RT_DEV f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
 RT_DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 RT_DEV f3 div3(f3 a, float s) { return (1.0f / s) * a; }
-RT_DEV f3 normalize3(f3 v) { return div3(v, sqrtf(dot3(v, v))); }
+
+// The correctly rounded square root, as sqrtf() gives it under -fhip-fp32-correctly-rounded-divide-sqrt, in fewer
+// instructions when every lane of the wave that is here holds an ordinary value.  The compiler's expansion scales
+// arguments below 2^-96 up before the hardware's 1-ulp v_sqrt_f32 and the result back down, settles the last bit with
+// two fused residuals (s -+ 1 ulp against x), and puts zeros and infinities back at the end: sixteen instructions.  For
+// 2^-96 <= x < infinity the scaling and the fix-up are identities, and what is left — the middle of that same sequence,
+// so the same bits — is nine.  One vote per call picks the sequence for the whole wave.
+#ifndef RT_SHORT_SQRT
+#define RT_SHORT_SQRT 1
+#endif
+RT_DEV float sqrt_rn(float x) {
+#if RT_SHORT_SQRT
+  const bool ordinary = (__float_as_uint(x) - 0x0F800000u) < (0x7F800000u - 0x0F800000u);  // also false for negatives and NaN
+  if (__builtin_amdgcn_ballot_w64(!ordinary) != 0ull) return sqrtf(x);
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float down = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+  const float r_down = __builtin_fmaf(-down, s, x), r_up = __builtin_fmaf(-up, s, x);
+  s = r_down <= 0.0f ? down : s;
+  s = r_up > 0.0f ? up : s;
+  return s;
+#else
+  return sqrtf(x);
+#endif
+}
+RT_DEV f3 normalize3(f3 v) { return div3(v, sqrt_rn(dot3(v, v))); }
 RT_DEV f3 reflect3(f3 I, f3 N) { return I - (2.0f * dot3(N, I)) * N; }
 RT_DEV f3 refract3(f3 I, f3 N, float eta) {
   float ni = dot3(N, I);
   float k = 1.0f - eta * eta * (1.0f - ni * ni);
   if (k < 0.0f) return mk3(0.0f, 0.0f, 0.0f);
-  return eta * I - (eta * ni + sqrtf(k)) * N;
+  return eta * I - (eta * ni + sqrt_rn(k)) * N;
 }
 RT_DEV float pow5(float x) {
   float x2 = x * x;
@@ -126,7 +150,7 @@ RT_DEV f3 random_unit_vector(uint32_t& a, lane_counters& k) {
     if (0.0f < lensq && lensq <= 1.0f) break;
     i += 1u;
   }
-  return div3(p, sqrtf(lensq));
+  return div3(p, sqrt_rn(lensq));
 }
 
 // testFragment.fs:368-383: point of the unit quarter-disk, not normalised.
@@ -164,7 +188,7 @@ RT_DEV bool near_zero3(f3 v) {  // fs:400-403
 template <bool COUNTED>
 RT_DEV float sphere_roots(float h, float disc, float a, lane_counters& k) {
   RT_COUNT(k, roots, 1);
-  float sq = sqrtf(disc);
+  float sq = sqrt_rn(disc);
   float t = (h - sq) / a;
   if (t < 0.001f) {
     RT_COUNT(k, roots, 1);
@@ -353,7 +377,7 @@ RT_DEV bool shade_hit(const hit_rec& h, int type, float param1, f3 m_albedo, per
     f3 unit_normal = normalize3(h.normal);
     float cos_theta = dot3(-unit_dir, h.normal);
     cos_theta = (1.0f < cos_theta) ? 1.0f : cos_theta;  // min(x, 1.0)
-    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    float sin_theta = sqrt_rn(1.0f - cos_theta * cos_theta);
     bool cannot_refract = ri * sin_theta > 1.0f;
     bool refl = cannot_refract;
     if (!refl) refl = schlick(cos_theta, ri) > rng_float<RNG>(rng);  // no draw on total internal reflection
