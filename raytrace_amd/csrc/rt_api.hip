@@ -167,6 +167,7 @@ struct rt_ctx {
   dev_buf<float4> leaf_sph;
   dev_buf<float> leaf_r;
   dev_buf<int32_t> leaf_idx;
+  dev_buf<float4> leaf_rec;   // trees read from HBM: two float4 per leaf (scene_dev::leaf_rec)
   float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
   float r_max = 0.0f, r_min = 0.0f, r_median = 0.0f, abs_max = 0.0f;
 
@@ -230,6 +231,7 @@ struct rt_ctx {
     s.qnodes = qnodes.p;
     s.leaf_sph = leaf_sph.p;
     s.leaf_idx = leaf_idx.p;
+    s.leaf_rec = leaf_rec.p;
     s.root = root;
     for (int a = 0; a < 3; a++) {
       s.root_lo[a] = root_lo[a];
@@ -1379,7 +1381,7 @@ void rt_destroy(rt_ctx* c) {
   c->sph.release(); c->inv_r.release(); c->sph_mat.release(); c->mat_type.release(); c->mat_a.release();
   c->quad_qd.release(); c->quad_u.release(); c->quad_v.release(); c->quad_n.release(); c->quad_w.release(); c->quad_idx.release(); c->quad_of.release();
   c->big_sph.release(); c->big_idx.release(); c->tree_sph.release(); c->tree_r.release(); c->tree_orig.release();
-  c->nodes.release(); c->qnodes.release(); c->leaf_sph.release(); c->leaf_r.release(); c->leaf_idx.release();
+  c->nodes.release(); c->qnodes.release(); c->leaf_sph.release(); c->leaf_r.release(); c->leaf_idx.release(); c->leaf_rec.release();
   c->accum_own.release(); c->seed_tex.release(); c->queue.release(); c->counters.release(); c->ovf.release(); c->build.release(); c->perlin_grad.release();
   c->carry_colour.release(); c->carry_rng.release(); c->carry_cost.release(); c->carry_key.release(); c->carry_idx.release();
   c->plan_parts.release(); c->plan_first.release(); c->plan_counts.release(); c->plan_total.release();
@@ -1614,6 +1616,15 @@ int upload_impl(rt_ctx* c, const void* spheres_std140, size_t n_bytes, int n_sph
     lbvh_quantize_kernel<<<(unsigned)((c->n_nodes + 255) / 256), 256, 0, c->stream>>>(c->nodes.p, c->n_nodes, c->qnodes.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  if ((c->search == SEARCH_TREE_GLB_RAY || c->search == SEARCH_TREE_GLB_NODE || c->search == SEARCH_TREE_GLB_NODE_Q) && c->n_leaf > 0) {
+    HIP_TRY(c->leaf_rec.resize(2 * (size_t)c->n_leaf));
+    lbvh_pack_leaves_kernel<<<(unsigned)((c->n_leaf + 255) / 256), 256, 0, c->stream>>>(c->leaf_sph.p, c->leaf_idx.p, c->inv_r.p, c->n_leaf,
+                                                                                        c->leaf_rec.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  } else {
+    c->leaf_rec.release();
   }
   c->have_scene = true;
   return RT_OK;

@@ -176,6 +176,7 @@ RT_DEV void search_setup(const scene_dev& sc, scene_view& sv, uint32_t*& stack_c
   sv.qnodes = sc.qnodes;
   sv.leaf_sph = sc.leaf_sph;
   sv.leaf_idx = sc.leaf_idx;
+  sv.leaf_rec = sc.leaf_rec;
   sv.scan_sph = sc.sph;
   sv.sph = sc.sph;
   sv.inv_r = sc.inv_r;
@@ -1029,9 +1030,17 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       float tt = -1.0f;
       if (t > 0.001f) {
         RT_COUNT(k, hits, 1);
-        const float4 sp = sv.sph[idx];
+        float4 sp;
+        float inv_r;
+        if (search_traits<SEARCH>::staged && srch.ts.best_pos >= 0) {  // the leaf's own record holds both (one request, not two)
+          sp = sv.leaf_rec[2 * (size_t)srch.ts.best_pos];
+          inv_r = sv.leaf_rec[2 * (size_t)srch.ts.best_pos + 1].y;
+        } else {
+          sp = sv.sph[idx];
+          inv_r = sv.inv_r[idx];
+        }
         const f3 p = o + d * t;
-        n = sv.inv_r[idx] * (p - mk3(sp.x, sp.y, sp.z));
+        n = inv_r * (p - mk3(sp.x, sp.y, sp.z));
         if (search_traits<SEARCH>::quads && sp.w == -__builtin_inff()) {
           const float4 qn = sc.quad_n[sc.quad_of[idx]];
           n = mk3(qn.x, qn.y, qn.z);

@@ -297,6 +297,16 @@ __global__ __launch_bounds__(256) void lbvh_collapse_level_kernel(const float4* 
   nodes[slot] = nd;
 }
 
+// Leaf records of trees read from HBM (scene_dev::leaf_rec): the sphere, its upload index and 1 / r side by side.
+__global__ __launch_bounds__(256) void lbvh_pack_leaves_kernel(const float4* leaf_sph, const int32_t* leaf_idx, const float* inv_r, int n,
+                                                              float4* leaf_rec) {
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  if (pos >= n) return;
+  const int idx = leaf_idx[pos];
+  leaf_rec[2 * (size_t)pos] = leaf_sph[pos];
+  leaf_rec[2 * (size_t)pos + 1] = make_float4(__uint_as_float((uint32_t)idx), inv_r[idx], 0.0f, 0.0f);
+}
+
 // ---- 64-byte nodes for trees read from HBM ------------------------------------
 // One thread per 4-wide node: the children's boxes onto a byte grid over their union (bvh4q_node).  Low planes are
 // rounded down and high planes up, checked in double against the decoded value, so that the decoded box holds the

@@ -72,6 +72,10 @@ struct scene_dev {
   const bvh4q_node* qnodes; // trees read from HBM
   const float4* leaf_sph;   // Morton order
   const int32_t* leaf_idx;  // Morton position -> upload index
+  // Trees read from HBM: everything a leaf test and the hit record need of a sphere in 32 bytes of one 64-byte half
+  // line — (cx, cy, cz, r*r), (upload index as bits, 1/r, -, -) at [2 pos], [2 pos + 1] — where leaf_sph, leaf_idx, sph
+  // and inv_r are four arrays and four fabric requests.  Null for trees held in LDS.
+  const float4* leaf_rec;
   int32_t root;             // reference of the root (a leaf reference when n_leaf == 1)
   float root_lo[3], root_hi[3];  // bounds of the tree's spheres
   float r_max;              // largest radius in the tree
@@ -91,6 +95,7 @@ struct scene_view {
   const bvh4q_node* qnodes;
   const float4* leaf_sph;
   const int32_t* leaf_idx;
+  const float4* leaf_rec;
   const float4* scan_sph;   // upload-order spheres for the linear scan
   // hit record and shading, upload order
   const float4* sph;
@@ -336,28 +341,34 @@ struct trav_candidate {
 };
 
 // Exact test of one sphere against the running closest hit.
+// Returns whether the sphere became the closest hit.
 template <bool COUNTED>
-RT_DEV void consider_sphere(float4 s, int upload_index, f3 o, f3 d, float a, trav_candidate& c, lane_counters& k) {
+RT_DEV bool consider_sphere(float4 s, int upload_index, f3 o, f3 d, float a, trav_candidate& c, lane_counters& k) {
   RT_COUNT(k, sphere_tests, 1);
   float h, disc;
   sphere_disc(s.x, s.y, s.z, s.w, o, d, a, h, disc);
+  bool taken = false;
   if (disc >= 0.0f) {
     float t = sphere_roots<COUNTED>(h, disc, a, k);
     if (t != t || t == 0.001f) c.give_up();
     if (t > 0.001f && (t < c.best_t || (t == c.best_t && upload_index < c.best_i))) {
       c.best_t = t;
       c.best_i = upload_index;
+      taken = true;
     }
   }
+  return taken;
 }
 
 // The same for a quad leaf (trees of scenes with quads).
-RT_DEV void consider_quad(const scene_dev& sc, int upload_index, f3 o, f3 d, trav_candidate& c) {
+RT_DEV bool consider_quad(const scene_dev& sc, int upload_index, f3 o, f3 d, trav_candidate& c) {
   const float t = hit_quad(load_quad(sc, sc.quad_of[upload_index]), o, d);
   if (t > 0.001f && (t < c.best_t || (t == c.best_t && upload_index < c.best_i))) {
     c.best_t = t;
     c.best_i = upload_index;
+    return true;
   }
+  return false;
 }
 
 // Per-ray constants of the PAD_RAY slab test: t_lo = lo*inv_d + k_lo, t_hi = hi*inv_d + k_hi.
@@ -604,6 +615,7 @@ struct tree_search {
   slab_consts sl;
   trav_candidate c;
   int cur, sp;  // cur: node to test next, -1 when the stack has run dry
+  int best_pos; // trees read from HBM: the closest hit's place in leaf_rec, -1 while it is none of the tree's spheres
   static constexpr bool LEAF_INLINE = PACKED && !RT_LDS_LEAF_STEPS;
   static constexpr bool SELECT = PAD_RAY && PACKED;  // planes picked by direction sign (slab_consts)
   leaf_queue<PACKED> lq;
@@ -621,6 +633,7 @@ struct tree_search {
     c.best_i = -1;
     sp = 0;
     cur = -1;
+    best_pos = -1;
     if (!LEAF_INLINE) lq.clear();
     if (!(a > 0.0f) || !(a < __builtin_inff())) {  // zero, NaN or overflowing direction: the scan decides
       c.give_up();
@@ -654,6 +667,19 @@ struct tree_search {
 
   // Exact test of the leaf at a position of the tree's order: a sphere, or (scenes with quads) a quad.
   RT_DEV void consider_leaf(const scene_dev& sc, const scene_view& sv, int pos, lane_counters& k) {
+    if (!PACKED) {  // one 32-byte record: sphere, upload index, 1 / r
+      const float4 rec = sv.leaf_rec[2 * (size_t)pos], aux = sv.leaf_rec[2 * (size_t)pos + 1];
+      const int idx = (int)__float_as_uint(aux.x);
+      bool taken;
+      if (QUADS && rec.w == -__builtin_inff()) {
+        RT_COUNT(k, sphere_tests, 1);
+        taken = consider_quad(sc, idx, o, d, c);
+      } else {
+        taken = consider_sphere<COUNTED>(rec, idx, o, d, a, c, k);
+      }
+      if (taken) best_pos = pos;
+      return;
+    }
     const float4 rec = sv.leaf_sph[pos];
     if (QUADS && rec.w == -__builtin_inff()) {
       RT_COUNT(k, sphere_tests, 1);
@@ -875,6 +901,7 @@ struct tree_search {
 
   RT_DEV void finish(const scene_dev& sc, const scene_view& sv, float& t_out, int& i_out, lane_counters& k) {
     if (c.redo()) {
+      best_pos = -1;
       hit_linear_lean<COUNTED>(sv.scan_sph, sc.n_spheres, o, d, t_out, i_out, k);
       if (QUADS) hit_quads_linear(sc, o, d, t_out, i_out);
       return;
