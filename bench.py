@@ -47,16 +47,27 @@ CONFIGS = {
 }
 
 
-def measured_traffic(kernel, workload):
-    """HBM bytes per step from the committed counter passes (profiles/pmc_traffic.json, written by
-    tools/pmc_traffic.py from `rocprofv3 --pmc` runs of this same command), or None when that
-    workload has not been profiled.  Counters cannot be read from inside the timed run."""
+# Read requests per second that L2 gets answered by the fabric behind it, measured with kernels that do nothing else
+# (tools/microbench/fetch_calib, profiles/r2_fetch_calibration.txt): 53.3 - 54.9 G/s for 64-byte gathers at random
+# over 1 GiB, 48 G/s of 128-byte requests for streamed reads.  The ceiling of a batch of incoherent tree walks.
+FABRIC_REQUEST_CEILING_GPS = 54.0
+
+
+def traffic_record(kernel, workload):
+    """The committed counter passes of this command (profiles/pmc_traffic.json, written by tools/pmc_traffic.py from
+    `rocprofv3 --pmc` runs), or None when that workload has not been profiled.  Counters cannot be read from inside
+    the timed run."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            rec = json.load(f).get(f"{kernel}|{workload}")
+            return json.load(f).get(f"{kernel}|{workload}")
     except (OSError, ValueError):
         return None
+
+
+def measured_traffic(kernel, workload):
+    """HBM bytes per step from those passes, or None."""
+    rec = traffic_record(kernel, workload)
     return rec["hbm_bytes_per_step"] if rec else None
 
 
@@ -103,8 +114,10 @@ def traffic_source():
             meta = json.load(f).get("_meta", {})
     except (OSError, ValueError):
         return None
-    return ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, (2*FETCH_SIZE + WRITE_SIZE)*1024 B "
-            f"per step, collected {meta.get('date', '?')} at commit {meta.get('commit', '?')}; not measured in this run")
+    return ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per kernel "
+            "(factor*FETCH_SIZE + WRITE_SIZE)*1024 B with the factor calibrated on known-byte kernels (2 for streamed reads, which the "
+            "counter halves; 1 for the closest-hit kernel's 64-byte node gathers, which it counts exactly), "
+            f"collected {meta.get('date', '?')} at commit {meta.get('commit', '?')}; not measured in this run")
 
 
 def cpu_baseline_render(rt, scene, cam, cfg, threads):
@@ -376,6 +389,16 @@ def main():
                                   "unit": "TFLOP/s", "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
                                   "kernel": kname, "kernel_ms": avg_kernel_ms,
                                   "algorithmic_gflop_per_launch": flops / 1e9}
+        rec = traffic_record(kname, result["config"]["workload"])
+        if args.config == "c4" and rec and rec.get("fabric_read_requests_per_step"):
+            # what bounds an incoherent batch: every L2 miss of a node or leaf read is one read request to the fabric
+            req = rec["fabric_read_requests_per_step"] * (n / max(rec.get("rays_per_step", n), 1))
+            rate = req / (avg_kernel_ms * 1e-3) / 1e9
+            result["roofline"]["fabric_requests"] = {
+                "per_ray": req / max(n, 1), "achieved": rate, "ceiling": FABRIC_REQUEST_CEILING_GPS, "unit": "G requests/s",
+                "frac": rate / FABRIC_REQUEST_CEILING_GPS,
+                "source": "requests: TCC_EA0_RDREQ pass in profiles/pmc_traffic.json (not measured in this run); ceiling: random "
+                          "64-byte gathers of tools/microbench/fetch_calib, profiles/r2_fetch_calibration.txt"}
         if traffic:  # fabric bytes (Infinity Cache + HBM reads behind L2, and writes) per second of kernel time
             result["roofline"]["traffic_gbs"] = traffic / (avg_kernel_ms * 1e-3) / 1e9
             result["roofline"]["traffic_source"] = traffic_source()

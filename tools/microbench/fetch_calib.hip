@@ -7,6 +7,8 @@
 //                       (rt_sum_split_kernel on paired records)
 //   calib_gather64      groups of four lanes read one 64-byte node each, nodes chosen at random in a 1 GiB table
 //                       (stage_nodes: the closest-hit kernel's node fetch), with plain loads
+//   calib_gather64_cached   the same gathers over a 64 MiB table, which stays in the Infinity Cache (the closest-hit
+//                       kernel's tree does): the rate at which L2 misses are answered from there
 //   calib_gather64_lds  the same through loads that write LDS directly, as stage_nodes issues them
 //   calib_halfline      every workgroup reads the even 64-byte halves of a private 128 KiB region, then the odd halves:
 //                       fabric read requests = lines if a miss of half a line fills the whole 128-byte line,
@@ -57,6 +59,17 @@ __global__ __launch_bounds__(256) void calib_pair32(const float4* src, size_t n_
 
 // node_mask + 1 nodes of 64 bytes; gather g of the launch reads node mix(g) & node_mask
 __global__ __launch_bounds__(256) void calib_gather64(const float4* table, uint32_t node_mask, size_t n_gathers, float* sink) {
+  float s = 0.0f;
+  const uint32_t sub = threadIdx.x & 3u;
+  for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < 4 * n_gathers; t += (size_t)gridDim.x * 256) {
+    const uint32_t node = mix((uint32_t)(t >> 2) * 2654435761u + 12345u) & node_mask;
+    const float4 v = table[(size_t)node * 4 + sub];
+    s += v.x + v.w;
+  }
+  if (s == 12345.678f) sink[0] = s;
+}
+
+__global__ __launch_bounds__(256) void calib_gather64_cached(const float4* table, uint32_t node_mask, size_t n_gathers, float* sink) {
   float s = 0.0f;
   const uint32_t sub = threadIdx.x & 3u;
   for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < 4 * n_gathers; t += (size_t)gridDim.x * 256) {
@@ -151,6 +164,8 @@ int main() {
   timed("calib_stream16", (double)bytes, [&] { calib_stream16<<<grid, 256>>>(buf, bytes / 16, sink); });
   timed("calib_pair32", (double)bytes, [&] { calib_pair32<<<grid, 256>>>(buf, bytes / 32, sink); });
   timed("calib_gather64", (double)n_gathers * 64.0, [&] { calib_gather64<<<grid, 256>>>(table, node_mask, n_gathers, sink); });
+  // the same gathers over 64 MiB, which the Infinity Cache holds: known_bytes is what is asked for, not what HBM gives
+  timed("calib_gather64_cached", (double)n_gathers * 64.0, [&] { calib_gather64_cached<<<grid, 256>>>(table, (uint32_t)(((size_t)64 << 20) / 64 - 1), n_gathers, sink); });
   timed("calib_gather64_lds", (double)n_gathers * 64.0, [&] { calib_gather64_lds<<<grid, 256>>>(table, node_mask, n_gathers, sink); });
   timed("calib_halfline", (double)halfline_blocks * 1024.0 * 128.0, [&] { calib_halfline<<<halfline_blocks, 256>>>(table, sink); });
   timed("calib_write16", (double)bytes, [&] { calib_write16<<<grid, 256>>>(buf, bytes / 16); });

@@ -60,17 +60,24 @@ def main():
         for r in write:
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             per_kernel.setdefault(k, [0.0, 0.0])[1] += float(r["Counter_Value"])
+        requests = {}
         total = sum((read_factor(k) * v[0] + v[1]) * 1024 for k, v in per_kernel.items())
         rays = bench["config"].get("rays")
         if rays:  # the streamed half of the ray input that the counter does not show
             total += 12.0 * rays
+            requests["rays_per_step"] = rays
+        req_path = os.path.join(d, "req_counter_collection.csv")
+        if os.path.exists(req_path):
+            for counter, label in (("TCC_EA0_RDREQ_sum", "fabric_read_requests_per_step"), ("TCC_REQ_sum", "l2_requests_per_step"),
+                                   ("TCC_HIT_sum", "l2_hits_per_step")):
+                requests[label] = sum(float(r["Counter_Value"]) for r in timed_step_rows(req_path, counter))
         key = bench["roofline"]["kernel"] + "|" + bench["config"]["workload"]
         out[key] = {
             "hbm_bytes_per_step": total,
             "uncalibrated_2x_fetch_plus_write": (2 * f_kib + w_kib) * 1024,
             "read_factor_per_kernel": {k: read_factor(k) for k in per_kernel},
             "fetch_size_kib": f_kib, "write_size_kib": w_kib,
-            "dispatches_per_step": len(fetch),
+            "dispatches_per_step": len(fetch), **requests,
             "per_kernel_kib_fetch_write": {k: v for k, v in per_kernel.items()},
             "source": f"rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE / --pmc WRITE_SIZE, bench.py --steps 1 --warmup 0, timed step only",
         }

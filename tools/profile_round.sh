@@ -18,5 +18,8 @@ for w in "c2_lbvh --steps 1 --warmup 0" "c2_linear --accel linear --steps 1 --wa
   set -- $w; name=$1; shift
   run timeout -s KILL 200 rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d $out/pmc_$name -o fetch -- python3 $root/bench.py "$@" --no-cpu-baseline --no-extras > $out/pmc_$name.fetch.json 2> $out/pmc_$name.fetch.err
   run timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_$name -o write -- python3 $root/bench.py "$@" --no-cpu-baseline --no-extras > $out/pmc_$name.write.json 2> $out/pmc_$name.write.err
+  # read requests of L2 to the fabric, and L2's own requests and hits (the closest-hit batch is bound by the first)
+  run timeout -s KILL 200 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_REQ_sum TCC_HIT_sum --output-format csv -d $out/pmc_$name -o req -- python3 $root/bench.py "$@" --no-cpu-baseline --no-extras > $out/pmc_$name.req.json 2> $out/pmc_$name.req.err
 done
+python3 $root/tools/pmc_traffic.py $out c2_lbvh c2_linear c3 c4 > $out/pmc_traffic.json || echo "pmc_traffic.py failed"
 ls -R $out | head -60
