@@ -48,9 +48,10 @@ CONFIGS = {
 
 
 # Read requests per second that L2 gets answered by the fabric behind it, measured with kernels that do nothing else
-# (tools/microbench/fetch_calib, profiles/r2_fetch_calibration.txt): 53.3 - 54.9 G/s for 64-byte gathers at random
-# over 1 GiB, 48 G/s of 128-byte requests for streamed reads.  The ceiling of a batch of incoherent tree walks.
-FABRIC_REQUEST_CEILING_GPS = 54.0
+# (tools/microbench/fetch_calib, profiles/r2_fetch_calibration.txt): 54.6 - 55.7 G/s for 64-byte gathers at random, one
+# or four in flight per lane, over 1 GiB (HBM) as over 64 MiB (Infinity Cache); 48 G/s of 128-byte requests for
+# streamed reads.  The ceiling of a batch of incoherent tree walks, whose every L2 miss is such a request.
+FABRIC_REQUEST_CEILING_GPS = 55.7
 
 
 def traffic_record(kernel, workload):

@@ -474,12 +474,6 @@ RT_DEV float byte_of(uint32_t w, int ch) { return (float)((w >> (8 * ch)) & 255u
 #ifndef RT_STAGE_DMA
 #define RT_STAGE_DMA 1
 #endif
-#ifndef RT_POP_PIN_LDS
-#define RT_POP_PIN_LDS 1
-#endif
-#ifndef RT_Q_SELECT
-#define RT_Q_SELECT 1
-#endif
 #define RT_STAGE_ROW 1040   // 64 lanes x 16 bytes + 16: the rows start in different banks
 #define RT_STAGE_BYTES (RT_STAGE_PIECES * RT_STAGE_ROW + (RT_STAGE_PIECES == 4 ? 0 : 256))  // (+ the wanted list of groups of eight)
 extern __shared__ __attribute__((aligned(16))) unsigned char rt_lds[];
@@ -727,7 +721,6 @@ struct tree_search {
         const float kx = sx * sl.inv_d.x, ky = sy * sl.inv_d.y, kz = sz * sl.inv_d.z;
         const float ax = (rx - pad) * sl.inv_d.x, ay = (ry - pad) * sl.inv_d.y, az = (rz - pad) * sl.inv_d.z;
         const float bx = (rx + pad) * sl.inv_d.x, by = (ry + pad) * sl.inv_d.y, bz = (rz + pad) * sl.inv_d.z;
-#if RT_Q_SELECT
         // Planes picked by the sign of the direction: with a negative 1/d the high plane is the one the ray enters by,
         // and (fma being monotonic in each argument, low bytes <= high bytes, a <= b exactly when 1/d is positive) the
         // picked parameters are bit for bit the min and the max of the two — twelve selects per node for 24 min / max.
@@ -744,16 +737,6 @@ struct tree_search {
           tn[ch] = fmaxf(fmaxf(fmaxf(t0x, t0y), t0z), RT_T_FLOOR);
           tf[ch] = fminf(fminf(fminf(t1x, t1y), t1z), c.best_t);
         }
-#else
-#pragma unroll
-        for (int ch = 0; ch < 4; ch++) {
-          const float t0x = __builtin_fmaf(byte_of(p1.x, ch), kx, ax), t1x = __builtin_fmaf(byte_of(p1.w, ch), kx, bx);
-          const float t0y = __builtin_fmaf(byte_of(p1.y, ch), ky, ay), t1y = __builtin_fmaf(byte_of(p2.x, ch), ky, by);
-          const float t0z = __builtin_fmaf(byte_of(p1.z, ch), kz, az), t1z = __builtin_fmaf(byte_of(p2.y, ch), kz, bz);
-          tn[ch] = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), RT_T_FLOOR);
-          tf[ch] = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), c.best_t);
-        }
-#endif
       }
     } else {
       ref = reinterpret_cast<const int4*>(nd)[6];
@@ -888,9 +871,9 @@ struct tree_search {
       // The LDS row is read unconditionally (row clamped) and replaced by the overflow row where
       // the entry lives there: a pointer chosen between the two memories would need flat loads.
       uint32_t e = stk.col[min(sp, STACK - 1) * 64];
-#if RT_POP_PIN_LDS
-      if (!PACKED) asm volatile("" : "+v"(e));  // the LDS read stays an LDS read: merged with the overflow read below it becomes a flat load
-#endif
+      // (the LDS read stays an LDS read: left to the compiler, the two reads become one flat load from a selected address,
+      // which waits on both memories' counters)
+      if (!PACKED) asm volatile("" : "+v"(e));
       if (!PACKED && sp >= STACK) e = sv.ovf_col[(size_t)(sp - STACK) * 64];
       if (stk.key_tn(e) <= c.best_t) {
         cur = stk.key_ref(e);
