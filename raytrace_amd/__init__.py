@@ -271,6 +271,20 @@ class Renderer:
         self._check(self.lib.rt_eval_perlin_gradient(self.ctx, ixy.ctypes.data, ixy.shape[0], out.ctypes.data))
         return out
 
+    def eval_sqrt(self, x):
+        """The kernels' square root (correctly rounded binary32) of float32 values, evaluated on the device."""
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+        out = np.empty_like(x)
+        self._check(self.lib.rt_eval_sqrt(self.ctx, x.ctypes.data, x.shape[0], out.ctypes.data))
+        return out
+
+    def check_sqrt(self, first_bits=0, count=1 << 32):
+        """(mismatches, example bits) of the kernels' square root against the compiler's correctly rounded one over
+        `count` bit patterns from `first_bits` on."""
+        bad, ex = ctypes.c_uint64(0), ctypes.c_uint32(0)
+        self._check(self.lib.rt_check_sqrt(self.ctx, first_bits, count, ctypes.byref(bad), ctypes.byref(ex)))
+        return int(bad.value), int(ex.value)
+
     def synchronize(self):
         self._check(self.lib.rt_synchronize(self.ctx))
 

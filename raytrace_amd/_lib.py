@@ -80,7 +80,7 @@ DEVICE_SYMBOLS = [
     "rt_clear", "rt_set_accumulator", "rt_set_accumulated_samples", "rt_readback", "rt_trace_batch",
     "rt_trace_batch_device", "rt_synchronize", "rt_get_counters", "rt_last_kernel_ms", "rt_last_build_ms",
     "rt_lbvh_depth", "rt_device_count", "rt_seed_texture", "rt_accumulator_read", "rt_accumulator_write",
-    "rt_render_chunk", "rt_trace_batch_noalloc", "rt_eval_perlin", "rt_eval_perlin_gradient", "rt_set_scratch_budget", "rt_get_scene_info", "rt_get_stream",
+    "rt_render_chunk", "rt_trace_batch_noalloc", "rt_eval_perlin", "rt_eval_perlin_gradient", "rt_eval_sqrt", "rt_check_sqrt", "rt_set_scratch_budget", "rt_get_scene_info", "rt_get_stream",
 ]
 HOST_SYMBOLS = ["rt_host_camera", "rt_host_build_scene", "rt_host_scene_object_bytes", "rt_host_scene_camera", "rt_host_gen_rays",
                 "rt_host_blit_nearest", "rt_host_height_for_width", "rt_host_write_ppm",
@@ -197,6 +197,11 @@ def device_lib():
         lib.rt_get_stream.argtypes = [ctypes.c_void_p, P(ctypes.c_void_p)]
         lib.rt_eval_perlin.restype = ctypes.c_int
         lib.rt_eval_perlin.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+        lib.rt_eval_sqrt.restype = ctypes.c_int
+        lib.rt_eval_sqrt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        lib.rt_check_sqrt.restype = ctypes.c_int
+        lib.rt_check_sqrt.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
+                                      ctypes.POINTER(ctypes.c_uint32)]
         lib.rt_eval_perlin_gradient.restype = ctypes.c_int
         lib.rt_eval_perlin_gradient.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         lib.rt_synchronize.restype = ctypes.c_int

@@ -1976,6 +1976,63 @@ int rt_eval_perlin_gradient(rt_ctx* c, const int32_t* ixy, size_t n, float* gxy)
   return RT_OK;
 }
 
+int rt_eval_sqrt(rt_ctx* c, const float* x, size_t n, float* y) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (n == 0) return RT_OK;
+  if (!x || !y) return fail(RT_ERR_INVALID, "null argument or result pointer");
+  if (n > ((size_t)1 << 28)) return fail(RT_ERR_INVALID, "too many values");
+  dev_buf<float> in, out;
+  hipError_t e = in.resize(n);
+  if (e == hipSuccess) e = out.resize(n);
+  if (e == hipSuccess) e = hipMemcpyAsync(in.p, x, n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    rt_eval_sqrt_kernel<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(in.p, n, out.p);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(y, out.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+  const hipError_t s = hipStreamSynchronize(c->stream);
+  in.release();
+  out.release();
+  if (e == hipSuccess) e = s;
+  if (e != hipSuccess) return fail(RT_ERR_DEVICE, "rt_eval_sqrt: %s", hipGetErrorString(e));
+  return RT_OK;
+}
+
+int rt_check_sqrt(rt_ctx* c, uint64_t first_bits, uint64_t count, uint64_t* mismatches, uint32_t* example_bits) {
+  int rc = check_ctx(c);
+  if (rc) return rc;
+  if (!mismatches) return fail(RT_ERR_INVALID, "null result pointer");
+  if (first_bits > 0xFFFFFFFFull || count > 0x100000000ull || first_bits + count > 0x100000000ull)
+    return fail(RT_ERR_INVALID, "bit patterns beyond 32 bits");
+  *mismatches = 0;
+  if (example_bits) *example_bits = 0;
+  if (count == 0) return RT_OK;
+  dev_buf<unsigned long long> bad;
+  dev_buf<uint32_t> ex;
+  hipError_t e = bad.resize(1);
+  if (e == hipSuccess) e = ex.resize(1);
+  if (e == hipSuccess) e = hipMemsetAsync(bad.p, 0, sizeof(unsigned long long), c->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(ex.p, 0, sizeof(uint32_t), c->stream);
+  if (e == hipSuccess) {
+    const unsigned long long blocks = (count + 255) / 256;
+    rt_check_sqrt_kernel<<<(unsigned)(blocks < 16384ull ? blocks : 16384ull), 256, 0, c->stream>>>(first_bits, count, bad.p, ex.p);
+    e = hipGetLastError();
+  }
+  unsigned long long n_bad = 0;
+  uint32_t one = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&n_bad, bad.p, sizeof(n_bad), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&one, ex.p, sizeof(one), hipMemcpyDeviceToHost, c->stream);
+  const hipError_t s = hipStreamSynchronize(c->stream);
+  bad.release();
+  ex.release();
+  if (e == hipSuccess) e = s;
+  if (e != hipSuccess) return fail(RT_ERR_DEVICE, "rt_check_sqrt: %s", hipGetErrorString(e));
+  *mismatches = n_bad;
+  if (example_bits) *example_bits = one;
+  return RT_OK;
+}
+
 int rt_synchronize(rt_ctx* c) {
   int rc = check_ctx(c);
   if (rc) return rc;

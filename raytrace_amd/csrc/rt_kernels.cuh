@@ -1069,6 +1069,24 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
   flush_counters<COUNTED>(A.counters, k);
 }
 
+// sqrt_rn against the compiler's correctly rounded sqrtf over a range of bit patterns (test entry point): counts the
+// arguments whose results differ in any bit (two NaNs count as equal) and keeps one of them.
+__global__ __launch_bounds__(256) void rt_check_sqrt_kernel(unsigned long long first, unsigned long long count, unsigned long long* mismatches,
+                                                           uint32_t* example) {
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * 256) {
+    const uint32_t bits = (uint32_t)(first + i);
+    const float x = __uint_as_float(bits), a = sqrt_rn(x), b = sqrtf(x);
+    if (__float_as_uint(a) != __float_as_uint(b) && !(a != a && b != b)) {
+      atomicAdd(mismatches, 1ull);
+      *example = bits;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void rt_eval_sqrt_kernel(const float* x, size_t n, float* y) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = sqrt_rn(x[i]);
+}
+
 // Fills the gradient table of the noise texture: one lattice point per thread.
 __global__ __launch_bounds__(256) void rt_perlin_table_kernel(float2* grad, int half) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, side = (size_t)(2 * half);

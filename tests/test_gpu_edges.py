@@ -237,3 +237,25 @@ def test_tiny_scratch_budgets_give_the_same_frame(renderer, split_mb, probe_mb):
         assert_same_f32(renderer.readback(rgb8=False)[0], oracle.resolve(acc6, 6)[0], "6 spp")
     finally:
         renderer.set_scratch_budget(0, 0)
+
+
+# ---- the kernels' square root ---------------------------------------------------------------------------------
+
+def test_short_square_root_is_the_correctly_rounded_one(renderer):
+    """The kernels take square roots with a shortened sequence wherever a whole wavefront holds ordinary arguments
+    (sqrt_rn in csrc/rt_device.cuh).  Held to the compiler's correctly rounded sqrtf over ALL 2^32 bit patterns on the
+    device, and to numpy's (IEEE, correctly rounded) on values around every boundary of the short path, in wavefronts
+    that are all ordinary and in mixed ones."""
+    bad, example = renderer.check_sqrt(0, 1 << 32)
+    assert bad == 0, f"{bad} arguments differ, e.g. bits {example:#010x}"
+    edge_bits = np.array([0x00000000, 0x00000001, 0x007FFFFF, 0x00800000, 0x0F7FFFFF, 0x0F800000, 0x0F800001, 0x3F7FFFFF, 0x3F800000,
+                          0x3F800001, 0x40490FDB, 0x7F7FFFFF, 0x7F800000, 0x7FC00000, 0x80000000, 0x80000001, 0xBF800000, 0xFF800000],
+                         dtype=np.uint32)
+    rng = np.random.default_rng(11)
+    ordinary = rng.integers(0x0F800000, 0x7F800000, size=64 * 512, dtype=np.uint32)      # whole wavefronts on the short path
+    mixed = np.concatenate([edge_bits, rng.integers(0, 1 << 32, size=64 * 512 - edge_bits.size, dtype=np.uint64).astype(np.uint32)])
+    for bits in (ordinary, mixed):
+        x = bits.view(np.float32)
+        with np.errstate(invalid="ignore"):
+            want = np.sqrt(x)
+        assert_same_f32(renderer.eval_sqrt(x), want, "sqrt")

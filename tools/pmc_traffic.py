@@ -90,4 +90,5 @@ def main():
                     "command": "tools/profile_round.sh (rocprofv3 --pmc passes of bench.py --steps 1 --warmup 0 --no-extras --no-cpu-baseline)"}
     print(json.dumps(out, indent=1))
 
-main()
+if __name__ == "__main__":
+    main()
