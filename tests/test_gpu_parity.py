@@ -427,6 +427,37 @@ def test_device_build_on_degenerate_clouds(renderer, monkeypatch):
     assert_same_f32(got[1][:1024], ref[1], "t vs CPU restatement")
 
 
+def test_hbm_tree_with_spheres_kept_out_of_it(renderer):
+    """A tree read from HBM takes a leaf's sphere, index and 1/r from one record, and the hit record from that same
+    record — unless the closest hit is one of the spheres kept out of the tree (much larger than the rest), whose
+    record lies in the upload-order arrays.  20 000 small spheres around two giants: rays that end on a giant, on a
+    small sphere in front of one, and on nothing; ids, t and normals are the scan's, bit for bit."""
+    materials = rt.build_scene(rt.SCENE_DEFAULT).materials
+    rng = np.random.default_rng(123)
+    small = rng.uniform(-40, 40, (20000, 3)).astype(np.float32)
+    centres = np.concatenate([np.array([[0.0, -60.0, 0.0], [55.0, 10.0, -5.0]], np.float32), small])
+    radii = np.concatenate([np.array([50.0, 30.0], np.float32), rng.uniform(0.2, 0.6, 20000).astype(np.float32)])
+    order = rng.permutation(len(radii))          # the giants somewhere in the middle of the upload order
+    scene = _scene_of(centres[order], radii[order], materials)
+    n_rays = 32768
+    o = rng.uniform(-45, 45, (n_rays, 3)).astype(np.float32)
+    d = (rng.normal(size=(n_rays, 3)) * rng.uniform(0.5, 2.0, (n_rays, 1))).astype(np.float32)
+    renderer.upload(scene, rt.ACCEL_LINEAR)
+    want = renderer.trace(o, d)
+    renderer.upload(scene, rt.ACCEL_LBVH)
+    info = renderer.scene_info()
+    assert not info["tree_in_lds"] and info["n_big"] == 2, info
+    got = renderer.trace(o, d)
+    giants = np.isin(want[0], np.flatnonzero(order < 2))
+    assert giants.sum() > n_rays // 20 and ((want[0] >= 0) & ~giants).sum() > n_rays // 20, (giants.sum(), (want[0] >= 0).sum())
+    assert np.array_equal(got[0], want[0]), f"{(got[0] != want[0]).sum()} hit ids differ"
+    assert_same_f32(got[1], want[1], "t")
+    assert_same_f32(got[2], want[2], "normal")
+    ref = oracle.trace(scene, o[:512], d[:512], threads=8)
+    assert np.array_equal(got[0][:512], ref[0])
+    assert_same_f32(got[2][:512], ref[2], "normal vs CPU restatement")
+
+
 def test_small_scenes_are_scanned(renderer, monkeypatch):
     """Up to 16 spheres the scan is faster than any tree, so an upload that asks for a tree gets the scan (no tree is
     built); the frame and a closest-hit batch are those of the tree, bit for bit."""
