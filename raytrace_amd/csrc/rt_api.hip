@@ -967,33 +967,35 @@ size_t stored_lds_bytes(const rt_ctx* c) {
   return pad16(search_lds_bytes<SEARCH>(counts_of(c))) + (size_t)search_traits<SEARCH>::waves * RT_RESERVE_BYTES;
 }
 
-template <int SEARCH, bool COUNTED, bool NOISE>
+template <int SEARCH, bool COUNTED, bool NOISE, bool OWNED>
 hipError_t launch_stored_noise(rt_ctx* c, hipStream_t st, render_args a) {
   using T = search_traits<SEARCH>;
   const int tw = a.p.tile_x1 - a.p.tile_x0, th = a.vrows;
   const size_t lds = stored_lds_bytes<SEARCH>(c);
   a.reserve_offset = (uint32_t)(lds - (size_t)T::waves * RT_RESERVE_BYTES);
-  hipError_t e = allow_lds(rt_render_stored_kernel<SEARCH, COUNTED, NOISE>, lds);
+  hipError_t e = allow_lds(rt_render_stored_kernel<SEARCH, COUNTED, NOISE, OWNED>, lds);
   if (e != hipSuccess) return e;
   int per_cu = 0;
-  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_stored_kernel<SEARCH, COUNTED, NOISE>, T::threads, lds);
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_stored_kernel<SEARCH, COUNTED, NOISE, OWNED>, T::threads, lds);
   if (e != hipSuccess) return e;
   if (per_cu < 1) per_cu = 1;
   const long long blocks = blocks_for<T::waves>(c, per_cu, tw, th, a);
   e = attach_overflow<SEARCH>(c, blocks, a.sc);
   if (e != hipSuccess) return e;
-  rt_render_stored_kernel<SEARCH, COUNTED, NOISE><<<dim3((unsigned)blocks), T::threads, lds, st>>>(a);
+  rt_render_stored_kernel<SEARCH, COUNTED, NOISE, OWNED><<<dim3((unsigned)blocks), T::threads, lds, st>>>(a);
   return hipGetLastError();
 }
 
-template <int SEARCH, bool COUNTED>
+template <int SEARCH, bool COUNTED, bool OWNED>
 hipError_t launch_stored_one(rt_ctx* c, hipStream_t st, render_args a) {
-  return c->have_noise ? launch_stored_noise<SEARCH, COUNTED, true>(c, st, a) : launch_stored_noise<SEARCH, COUNTED, false>(c, st, a);
+  return c->have_noise ? launch_stored_noise<SEARCH, COUNTED, true, OWNED>(c, st, a) : launch_stored_noise<SEARCH, COUNTED, false, OWNED>(c, st, a);
 }
 
+// owned: the form of the kernel whose lanes sum whole pixels in registers (a main pass with jobs that have no row in the store)
 template <int SEARCH>
-hipError_t launch_stored(rt_ctx* c, bool counted, hipStream_t st, const render_args& a) {
-  return counted ? launch_stored_one<SEARCH, true>(c, st, a) : launch_stored_one<SEARCH, false>(c, st, a);
+hipError_t launch_stored(rt_ctx* c, bool counted, bool owned, hipStream_t st, const render_args& a) {
+  if (owned) return counted ? launch_stored_one<SEARCH, true, true>(c, st, a) : launch_stored_one<SEARCH, false, true>(c, st, a);
+  return counted ? launch_stored_one<SEARCH, true, false>(c, st, a) : launch_stored_one<SEARCH, false, false>(c, st, a);
 }
 
 // Whether the uploaded scene's search leaves room in LDS for the reserves of rt_render_stored_kernel.
@@ -1128,19 +1130,19 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       default: return launch_render<SEARCH_LINEAR>(c, rp, counted, c->stream, ra);
     }
   };
-  auto launch_stored_pass = [&](const render_args& ra) -> hipError_t {
+  auto launch_stored_pass = [&](const render_args& ra, bool owned = false) -> hipError_t {
     used_stored = true;
     hipError_t qe = hipMemsetAsync(c->queue.p, 0, sizeof(unsigned long long), c->stream);
     if (qe != hipSuccess) return qe;
     switch (c->search) {
-      case SEARCH_TREE_LDS_RAY: return launch_stored<SEARCH_TREE_LDS_RAY>(c, counted, c->stream, ra);
-      case SEARCH_TREE_LDS_NODE: return launch_stored<SEARCH_TREE_LDS_NODE>(c, counted, c->stream, ra);
-      case SEARCH_TREE_GLB_RAY: return launch_stored<SEARCH_TREE_GLB_RAY>(c, counted, c->stream, ra);
-      case SEARCH_TREE_GLB_NODE: return launch_stored<SEARCH_TREE_GLB_NODE>(c, counted, c->stream, ra);
-      case SEARCH_TREE_GLB_NODE_Q: return launch_stored<SEARCH_TREE_GLB_NODE_Q>(c, counted, c->stream, ra);
-      case SEARCH_LINEAR_Q: return launch_stored<SEARCH_LINEAR_Q>(c, counted, c->stream, ra);
-      case SEARCH_LINEAR_LDS: return launch_stored<SEARCH_LINEAR_LDS>(c, counted, c->stream, ra);
-      default: return launch_stored<SEARCH_LINEAR>(c, counted, c->stream, ra);
+      case SEARCH_TREE_LDS_RAY: return launch_stored<SEARCH_TREE_LDS_RAY>(c, counted, owned, c->stream, ra);
+      case SEARCH_TREE_LDS_NODE: return launch_stored<SEARCH_TREE_LDS_NODE>(c, counted, owned, c->stream, ra);
+      case SEARCH_TREE_GLB_RAY: return launch_stored<SEARCH_TREE_GLB_RAY>(c, counted, owned, c->stream, ra);
+      case SEARCH_TREE_GLB_NODE: return launch_stored<SEARCH_TREE_GLB_NODE>(c, counted, owned, c->stream, ra);
+      case SEARCH_TREE_GLB_NODE_Q: return launch_stored<SEARCH_TREE_GLB_NODE_Q>(c, counted, owned, c->stream, ra);
+      case SEARCH_LINEAR_Q: return launch_stored<SEARCH_LINEAR_Q>(c, counted, owned, c->stream, ra);
+      case SEARCH_LINEAR_LDS: return launch_stored<SEARCH_LINEAR_LDS>(c, counted, owned, c->stream, ra);
+      default: return launch_stored<SEARCH_LINEAR>(c, counted, owned, c->stream, ra);
     }
   };
   // Passes whose every sample is stored run in the kernel that keeps camera rays in reserve (counter generator; a
@@ -1311,7 +1313,17 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       mainp.main_samples = main_samples;
       mainp.split_rows = n < max_split ? n : max_split;
       mainp.pairs = pairs;
-      e = all_rows ? launch_stored_pass(mainp) : launch(mainp, p);
+      // Not every pixel has a row: the same kernel in the form whose lanes sum whole pixels in registers (counter
+      // generator; RT_OWNED_RESERVE=0 keeps the kernel without reserves, for comparison)
+      static const bool owned_enabled = [] {
+        const char* e = getenv("RT_OWNED_RESERVE");
+        return !(e && e[0] == '0');
+      }();
+      // (a slot number's top bit marks a whole pixel's sample there, and the pixel's number takes 29 bits)
+      const bool owned = !all_rows && stored_ok && owned_enabled && n_rect <= (size_t)RT_TAG_PIXEL &&
+                         (unsigned long long)mainp.split_rows * (unsigned long long)main_samples < (1ull << 31);
+      if (owned) mainp.pairs = 0;
+      e = all_rows ? launch_stored_pass(mainp) : (owned ? launch_stored_pass(mainp, true) : launch(mainp, p));
       if (e == hipSuccess && splittable) {
         const uint32_t cand = n < max_split ? n : max_split;
         rt_sum_split_kernel<<<(cand + 255) / 256, 256, 0, c->stream>>>(c->order_idx.p, c->plan_parts.p, cand, c->carry_colour.p,

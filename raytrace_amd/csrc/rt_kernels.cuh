@@ -651,8 +651,18 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
 #define RT_REFILL_VOTE 40
 #define RT_REFILL_MIN 16
 #define RT_RESERVE_BYTES 2048  // per wave: two rows of 64 float4
+// OWNED: the main pass of a frame in which only some pixels (or none) are cut into jobs with stored samples.  A job
+// that is a whole pixel's sample range (RT_JOB_WHOLE) has no row in the store: the lane that takes it forms the
+// pixel's sum in registers, in sample order, as rt_render_kernel does — from the sum the probe carried, written to
+// the image after the job's last sample.  A lane walks a job's samples in order and one path at a time, so one
+// running sum per lane is enough; what travels with a ray in the reserve's slot word is, for such a job, the pixel
+// and whether the sample is the job's first or last (the job variables may be a job ahead of the path in flight).
+#define RT_TAG_WHOLE 0x80000000u
+#define RT_TAG_FIRST 0x40000000u
+#define RT_TAG_LAST 0x20000000u
+#define RT_TAG_PIXEL 0x1FFFFFFFu  // the tile's pixel number: the host keeps such passes to tiles below 2^29 pixels
 
-template <int SEARCH, bool COUNTED, bool NOISE>
+template <int SEARCH, bool COUNTED, bool NOISE, bool OWNED>
 __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARCH>::render_waves_per_simd) void rt_render_stored_kernel(const render_args A) {
   constexpr int RNG = RT_RNG_COUNTER;
   const rt_params& P = A.p;
@@ -678,19 +688,21 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
   // which this kernel has none to spare, merged at every join of the wave's loop):
   //   ALIVE a path is in flight, PENDING its finished search waits to be shaded, RESERVE the lane's reserve holds a
   //   camera ray, JOB_LEFT the lane's job has samples left, JOBS_DONE the queue is dry, DONE the lane is through
-  enum : uint32_t { ALIVE = 1u, PENDING = 2u, RESERVE = 4u, JOB_LEFT = 8u, JOBS_DONE = 16u, DONE = 32u };
+  //   JOB_FIRST (OWNED) no ray of the lane's job has been made yet
+  enum : uint32_t { ALIVE = 1u, PENDING = 2u, RESERVE = 4u, JOB_LEFT = 8u, JOBS_DONE = 16u, DONE = 32u, JOB_FIRST = 64u };
   uint32_t st = P.sample_end <= P.sample_begin ? DONE : 0u;
   // Records in pairs: a lane that finishes the first sample of a pair keeps its radiance in registers until the second
   // is done, then writes both records, one aligned 32-byte sector, in two stores back to back.  (A record written
   // alone leaves L2 as a sector of its own before its neighbour arrives: 32 bytes to HBM per 16-byte record.  Four
   // records at a time — a whole 64-byte half line per lane — cut the writes by another 8 % and the frame rate by
   // 0.8 %.)  Jobs begin at even samples, so a pair is one lane's.
-  const bool pairs = A.pairs != 0 && A.pass == 2;
+  const bool pairs = !OWNED && A.pairs != 0 && A.pass == 2;
   f3 held = mk3(0.0f, 0.0f, 0.0f);
+  f3 colour = mk3(0.0f, 0.0f, 0.0f);  // OWNED: the running sum of the whole pixel whose path is in flight
   auto has = [&](uint32_t bits) { return (st & bits) != 0u; };
   auto none = [&](uint32_t bits) { return (st & bits) == 0u; };
   int jx = 0, jy = 0, js = 0, js_end = 0;    // the job: pixel, next sample to make a ray for, end
-  uint32_t jrow = 0, jpixel = 0;             // its row in the store; its pixel index
+  uint32_t jrow = 0, jpixel = 0, jrect = 0;  // its row in the store; its pixel index in the image and in the tile
   uint32_t rng = 0, count = 0, cur_slot = 0, path_segments = 0;
   f3 alb = mk3(0.0f, 0.0f, 0.0f);
   uint32_t pool_next = 0, pool_end = 0;
@@ -724,7 +736,18 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       if (shade_finished<SEARCH, RNG, COUNTED, NOISE>(srch, sc, sv, P.bounce_limit, alb, rng, count, k)) {
         start_segment = true;
       } else {  // fs:132: the sample's radiance, and what the path cost
-        if (pairs && (cur_slot & RT_SLOT_HOLD) != 0u) {
+        if (OWNED && (cur_slot & RT_TAG_WHOLE) != 0u) {
+          colour = colour + alb;
+          if ((cur_slot & RT_TAG_LAST) != 0u) {  // the pixel's sum is complete
+            const uint32_t rp = cur_slot & RT_TAG_PIXEL;
+            const int px = P.tile_x0 + (int)(rp % (uint32_t)tw);
+            const int py = real_row((int)(rp / (uint32_t)tw), P.tile_y0, P.strip_count, P.strip_index);
+            float* dst = A.accum + 3 * ((size_t)py * (size_t)P.width + (size_t)px);
+            dst[0] = colour.x;
+            dst[1] = colour.y;
+            dst[2] = colour.z;
+          }
+        } else if (pairs && (cur_slot & RT_SLOT_HOLD) != 0u) {
           held = alb;
         } else {
           // (an odd record of a pair always follows its partner in this lane: jobs begin at even samples)
@@ -741,6 +764,10 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       srch.ts.d = mk3(r1.x, r1.y, r1.z);
       rng = __float_as_uint(r0.w);
       cur_slot = __float_as_uint(r1.w);
+      if (OWNED && (cur_slot & (RT_TAG_WHOLE | RT_TAG_FIRST)) == (RT_TAG_WHOLE | RT_TAG_FIRST)) {
+        const float* src = A.carry_colour + 3 * (size_t)(cur_slot & RT_TAG_PIXEL);  // the sum the probe pass left
+        colour = mk3(src[0], src[1], src[2]);
+      }
       alb = mk3(1.0f, 1.0f, 1.0f);
       count = 0;
       path_segments = 0;
@@ -787,7 +814,8 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
             }
             jy = real_row(vy, P.tile_y0, P.strip_count, P.strip_index);
             jpixel = (uint32_t)jy * (uint32_t)P.width + (uint32_t)jx;
-            if (jx < P.tile_x1 && vy < th && js < js_end) st |= JOB_LEFT;
+            jrect = rect_pixel;
+            if (jx < P.tile_x1 && vy < th && js < js_end) st |= JOB_LEFT | JOB_FIRST;
           }
         }
         if (has(JOB_LEFT)) {  // fs:117-131 for the job's next sample, into the reserve
@@ -797,6 +825,9 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
           const uint32_t s_rel = (uint32_t)(js - P.sample_begin);
           uint32_t slot = (uint32_t)sample_slot(s_rel, (size_t)jrow, rows);
           if (pairs) slot = (uint32_t)pair_slot(s_rel, (size_t)jrow, rows) | ((s_rel & 1u) == 0u && js + 1 < js_end ? RT_SLOT_HOLD : 0u);
+          if (OWNED && jrow == RT_JOB_WHOLE)
+            slot = RT_TAG_WHOLE | (has(JOB_FIRST) ? RT_TAG_FIRST : 0u) | (js + 1 < js_end ? 0u : RT_TAG_LAST) | jrect;
+          st &= ~JOB_FIRST;
           reserve[0] = make_float4(ro.x, ro.y, ro.z, __uint_as_float(r));
           reserve[64] = make_float4(rd.x, rd.y, rd.z, __uint_as_float(slot));
           st |= RESERVE;

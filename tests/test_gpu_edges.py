@@ -230,6 +230,10 @@ def test_tiny_scratch_budgets_give_the_same_frame(renderer, split_mb, probe_mb):
         renderer.clear()
         renderer.render(p)
         assert_same_f32(renderer.readback(rgb8=False)[0], want, f"budgets {split_mb} / {probe_mb} MiB")
+        if split_mb == 1:
+            # only some pixels have rows in the store: the main pass ran in the form of the stored-samples kernel whose
+            # lanes sum whole pixels in registers (and not in the kernel without camera rays in reserve)
+            assert renderer.last_kernel_ms()[1] == "rt_render_stored_kernel<lbvh4,lds,pad_ray>"
         few = rt.make_params(cam, 192, 108, 6, rng_mode=rt.RNG_COUNTER)    # whole frame in sweeps, or not
         renderer.clear()
         renderer.render(few)

@@ -25,9 +25,9 @@ def test_timed_step_leaves_out_the_counted_steps_trailing_sum(tmp_path):
     tool = load_tool()
     frame = lambda counted: [  # noqa: E731
         ("__amd_rocclr_fillBufferAligned", 1.0),
-        (f"void rt_render_stored_kernel<1, {counted}, false>(render_args)", 10.0),
+        (f"void rt_render_stored_kernel<1, {counted}, false, false>(render_args)", 10.0),
         ("rt_probe_sum_kernel(unsigned int)", 2.0),
-        (f"void rt_render_stored_kernel<1, {counted}, false>(render_args)", 100.0),
+        (f"void rt_render_stored_kernel<1, {counted}, false, false>(render_args)", 100.0),
         ("rt_sum_split_kernel(unsigned int const*)", 4000.0),
     ]
     path = tmp_path / "fetch_counter_collection.csv"
@@ -46,4 +46,4 @@ def test_read_factors():
     tool = load_tool()
     assert tool.read_factor("rt_trace_kernel<4, false>") == 1.0          # 64-byte node gathers: counted exactly
     assert tool.read_factor("rt_sum_split_kernel") == 2.0                # streamed reads: the counter shows half
-    assert tool.read_factor("rt_render_stored_kernel<1, false, false>") == 2.0
+    assert tool.read_factor("rt_render_stored_kernel<1, false, false, false>") == 2.0

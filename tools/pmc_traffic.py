@@ -21,11 +21,11 @@ import csv, json, os, sys
 MAIN = ("void rt_render_kernel<", "void rt_render_stored_kernel<", "void rt_trace_kernel<")
 
 
-def counted(name):  # rt_render_kernel<search, rng, counted, noise>, rt_render_stored_kernel<search, counted, noise>, rt_trace_kernel<search, counted>
+def counted(name):  # rt_render_kernel<search, rng, counted, noise>, rt_render_stored_kernel<search, counted, noise, owned>, rt_trace_kernel<search, counted>
     if not name.startswith(MAIN):
         return False
     args = [a.strip() for a in name[name.index("<") + 1:name.index(">")].split(",")]
-    return (args[-1] if name.startswith("void rt_trace_kernel<") else args[-2]) == "true"
+    return args[2 if name.startswith("void rt_render_kernel<") else 1] == "true"
 
 
 def timed_step_rows(path, counter):
