@@ -1,4 +1,5 @@
-"""The binding of INTEGRATION.md, compiled against the reference's own glad.h and linked with its src/glad.c
+"""The binding a maintainer of the reference would add — glad's function pointers pointed at the capture functions,
+without casts — compiled against the reference's own glad.h and linked with its src/glad.c
 (container only: skipped where /root/reference is absent, as on the GPU box).  Nothing of the reference is copied:
 its files are read where they lie and the outputs go to a temporary directory."""
 import os
