@@ -52,6 +52,11 @@ CONFIGS = {
 # or four in flight per lane, over 1 GiB (HBM) as over 64 MiB (Infinity Cache); 48 G/s of 128-byte requests for
 # streamed reads.  The ceiling of a batch of incoherent tree walks, whose every L2 miss is such a request.
 FABRIC_REQUEST_CEILING_GPS = 55.7
+# Vector instructions a SIMD issues per second at the render kernels' four waves per SIMD when multiplies and adds are
+# separate instructions, as the numerical contract makes them (tools/microbench/fma_rate.hip,
+# profiles/r1_microbench_fma_rate.txt: 47.1 T lane-instructions/s on the whole chip = one wave64 instruction per 3.34
+# cycles per SIMD; v_fma_f32 reaches one per 3.0 there)
+VALU_LANE_INSTS_PER_S_AT_4_WAVES = 47.1e12
 
 
 def traffic_record(kernel, workload):
@@ -400,6 +405,19 @@ def main():
                 "frac": rate / FABRIC_REQUEST_CEILING_GPS,
                 "source": "requests: TCC_EA0_RDREQ pass in profiles/pmc_traffic.json (not measured in this run); ceiling: random "
                           "64-byte gathers of tools/microbench/fetch_calib, profiles/r2_fetch_calibration.txt"}
+        try:  # what bounds the render kernels: the vector pipe's issue rate (counter passes of the same frame, committed)
+            with open(os.path.join(ROOT, "profiles", "r2_c2_issue.json")) as f:
+                issue = json.load(f).get(f"{kname}|{result['config']['workload']}")
+        except (OSError, ValueError):
+            issue = None
+        if issue and world == 1:
+            rate = issue["valu_insts_per_step"] * 64.0 / (avg_kernel_ms * 1e-3)
+            result["roofline"]["valu_issue"] = {
+                "wave_insts_per_step": issue["valu_insts_per_step"], "achieved": rate / 1e12, "limit": VALU_LANE_INSTS_PER_S_AT_4_WAVES / 1e12,
+                "unit": "T lane-instructions/s", "frac": rate / VALU_LANE_INSTS_PER_S_AT_4_WAVES,
+                "active_lanes_per_inst": issue["active_lanes_per_valu_inst"],
+                "source": "instructions: profiles/r2_c2_issue.json (SQ_INSTS_VALU passes, not measured in this run); limit: mul + add "
+                          "microbenchmark at 4 waves per SIMD, profiles/r1_microbench_fma_rate.txt"}
         if traffic:  # fabric bytes (Infinity Cache + HBM reads behind L2, and writes) per second of kernel time
             result["roofline"]["traffic_gbs"] = traffic / (avg_kernel_ms * 1e-3) / 1e9
             result["roofline"]["traffic_source"] = traffic_source()
