@@ -330,8 +330,13 @@ RT_API int rt_trace_batch_device(rt_ctx* ctx, const float* o_xyz, const float* d
  * whose depth lets the stack overflow of at least one workgroup per compute
  * unit fit the array (RT_ERR_INVALID otherwise: about depth 150 for the
  * HBM-resident trees; scenes held in LDS and the linear scan always fit).
+ * A refused call queues nothing and leaves rt_last_kernel_ms as it was.  When
+ * the context's stream is being captured (rt_get_stream) the call records the
+ * memset of the queue head and the kernel into the graph and no timing events:
+ * rt_last_kernel_ms then fails with RT_ERR_STATE until an uncaptured launch.
  * All calls on one GPU share that GPU's array: calls that overlap on one GPU
- * (two contexts, two streams) race; issue them one after another.
+ * (two contexts, two streams, two replays of a captured graph) race; issue them
+ * one after another.
  */
 #define RT_NOALLOC_SCRATCH_BYTES (64u << 20)
 #define RT_NOALLOC_MAX_RAYS 0x80000000ull
@@ -438,18 +443,6 @@ RT_API int rt_eval_perlin(rt_ctx* ctx, const float* xy, size_t n, int use_table,
  * the hashed angle); host pointers.
  */
 RT_API int rt_eval_perlin_gradient(rt_ctx* ctx, const int32_t* ixy, size_t n, float* gxy);
-
-/*
- * Replaces: nothing callable in the reference — GLSL's sqrt() inside hit_sphere, normalize() and refract()
- * (testFragment.fs:151, 246-287), which this library takes to be the correctly rounded binary32 square root.  The
- * kernels compute it with a shortened instruction sequence wherever a whole wavefront holds ordinary arguments;
- * these two entry points let a test hold that sequence to the full one.  rt_eval_sqrt: y[i] = that square root of
- * x[i], n values, host pointers.  rt_check_sqrt: over the `count` binary32 bit patterns from first_bits on (all
- * 2^32 in one call if asked), *mismatches = how many differ in any bit from the compiler's correctly rounded sqrtf
- * (two NaNs are equal) and *example_bits (nullable) = one of them.
- */
-RT_API int rt_eval_sqrt(rt_ctx* ctx, const float* x, size_t n, float* y);
-RT_API int rt_check_sqrt(rt_ctx* ctx, uint64_t first_bits, uint64_t count, uint64_t* mismatches, uint32_t* example_bits);
 
 /* Number of HIP devices visible (0 if none or the runtime cannot start). */
 RT_API int rt_device_count(void);

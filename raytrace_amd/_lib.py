@@ -80,8 +80,10 @@ DEVICE_SYMBOLS = [
     "rt_clear", "rt_set_accumulator", "rt_set_accumulated_samples", "rt_readback", "rt_trace_batch",
     "rt_trace_batch_device", "rt_synchronize", "rt_get_counters", "rt_last_kernel_ms", "rt_last_build_ms",
     "rt_lbvh_depth", "rt_device_count", "rt_seed_texture", "rt_accumulator_read", "rt_accumulator_write",
-    "rt_render_chunk", "rt_trace_batch_noalloc", "rt_eval_perlin", "rt_eval_perlin_gradient", "rt_eval_sqrt", "rt_check_sqrt", "rt_set_scratch_budget", "rt_get_scene_info", "rt_get_stream",
+    "rt_render_chunk", "rt_trace_batch_noalloc", "rt_eval_perlin", "rt_eval_perlin_gradient", "rt_set_scratch_budget", "rt_get_scene_info", "rt_get_stream",
 ]
+# ... and the test-only ones of include/raytrace_amd_test.h
+DEVICE_TEST_SYMBOLS = ["rt_eval_sqrt", "rt_check_sqrt"]
 HOST_SYMBOLS = ["rt_host_camera", "rt_host_build_scene", "rt_host_scene_object_bytes", "rt_host_scene_camera", "rt_host_gen_rays",
                 "rt_host_blit_nearest", "rt_host_height_for_width", "rt_host_write_ppm",
                 "rt_gl_bind_buffer", "rt_gl_buffer_sub_data", "rt_gl_buffer_data", "rt_gl_buffer_bytes", "rt_gl_reset"]

@@ -43,11 +43,28 @@ def _glob(d, exts):
     return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(exts))
 
 
-def build_device(force=False, extra_flags=()):
-    out = os.path.join(HERE, "libraytrace_amd.so")
-    deps = _glob(CSRC, (".hip", ".cuh", ".cpp")) + _glob(os.path.join(ROOT, "include"), (".h",))
-    if force or _newer(out, deps):
-        _run([HIPCC] + HIP_FLAGS + list(extra_flags) + ["-o", out, os.path.join(CSRC, "rt_api.hip"), os.path.join(CSRC, "rt_gl_capture.cpp")])
+DEVICE_SOURCES = ["rt_render_stored.hip", "rt_render_pixels.hip", "rt_api.hip", "rt_build.hip", "rt_render.hip", "rt_comm.hip", "rt_eval.hip", "rt_gl_capture.cpp"]
+
+
+def build_device(force=False, extra_flags=(), out=None, objdir=None, jobs=None):
+    """Every translation unit to an object of its own (side by side: rt_render.hip alone is most of the time), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+    out = out or os.path.join(HERE, "libraytrace_amd.so")
+    objdir = objdir or os.path.join(HERE, "build")
+    headers = _glob(CSRC, (".cuh", ".hpp")) + _glob(os.path.join(ROOT, "include"), (".h",))
+    os.makedirs(objdir, exist_ok=True)
+    compile_flags = [f for f in HIP_FLAGS if f != "-shared" and not f.startswith("-Wl,")] + list(extra_flags)
+    todo, objs = [], []
+    for src in DEVICE_SOURCES:
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [os.path.join(CSRC, src)] + headers):
+            todo.append([HIPCC] + compile_flags + ["-c", "-o", obj, os.path.join(CSRC, src)])
+    if todo:
+        with ThreadPoolExecutor(max_workers=jobs or min(len(todo), os.cpu_count() or 1)) as pool:
+            list(pool.map(_run, todo))
+    if todo or force or _newer(out, objs):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined", "-o", out] + objs)
     return out
 
 

@@ -29,9 +29,19 @@ def renderer():
 
 
 @pytest.fixture(autouse=True)
-def trees_for_small_scenes_too(monkeypatch):
-    """The library scans scenes of up to 16 spheres even when a tree is asked for (the scan is faster there).  The
-    tests ask for trees on the 6-sphere default scene and on scenes of two or three spheres precisely to exercise the
-    tree kernels on nodes with few children, so they lift that rule; test_small_scenes_are_scanned checks the rule
-    itself."""
+def tuning_switches_on(monkeypatch):
+    """The library reads its RT_* tuning switches only with RT_TUNING=1 in the environment; with that alone every
+    default stays as shipped.  Tests that set a switch (RT_BUILDER, RT_SCAN_UP_TO) rely on it."""
+    monkeypatch.setenv("RT_TUNING", "1")
+    monkeypatch.delenv("RT_SCAN_UP_TO", raising=False)
+    monkeypatch.delenv("RT_BUILDER", raising=False)
+
+
+@pytest.fixture
+def small_trees(monkeypatch):
+    """The library scans scenes of up to 16 spheres even when a tree is asked for (the scan is faster there).  Tests that
+    ask for trees on the 6-sphere default scene and on scenes of two or three spheres, precisely to exercise the tree
+    kernels on nodes with few children, lift that rule with this fixture; every other test runs the dispatch as
+    shipped, and test_small_scenes_are_scanned checks the rule itself."""
+    monkeypatch.setenv("RT_TUNING", "1")
     monkeypatch.setenv("RT_SCAN_UP_TO", "0")

@@ -19,8 +19,10 @@ def declared(header):
 def test_device_library_exports_every_declared_symbol():
     names = declared("raytrace_amd.h")
     assert len(names) >= 24 and set(_lib.DEVICE_SYMBOLS) == set(names)
+    test_names = declared("raytrace_amd_test.h")
+    assert set(_lib.DEVICE_TEST_SYMBOLS) == set(test_names) and not set(test_names) & set(names)
     lib = ctypes.CDLL(_lib.DEVICE_LIB)
-    for n in names:
+    for n in names + test_names:
         assert hasattr(lib, n), n
 
 

@@ -11,7 +11,8 @@ import pytest
 import oracle
 import raytrace_amd as rt
 
-pytestmark = pytest.mark.gpu
+# (small_trees: tree kernels also on the scenes of a few spheres that the library would scan, see conftest.py)
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("small_trees")]
 
 
 def _bits(a):

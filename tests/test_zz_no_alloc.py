@@ -60,3 +60,60 @@ def test_noalloc_equals_allocating_entry_point(scene_id, n_spheres, accel, kerne
         assert "at most" in str(err.value)
     finally:
         r.close()
+
+
+def _hip_runtime():
+    """The HIP runtime this process already uses (PyTorch's wheel carries its own copy: a second one would not know
+    the library's stream)."""
+    import ctypes
+    import torch  # noqa: F401  (loads the runtime)
+    with open("/proc/self/maps") as f:
+        paths = {line.split()[-1] for line in f if "libamdhip64.so" in line}
+    assert len(paths) == 1, paths
+    return ctypes.CDLL(paths.pop())
+
+
+def test_noalloc_call_can_be_captured_into_a_graph_and_replayed():
+    """The callers the entry point is for include code under HIP graph capture: captured on the context's own stream,
+    the call must queue only graph-safe work (a memset node and the kernel), and two replays of the graph, one after
+    the other, must each give rt_trace_batch_device's answers."""
+    import ctypes
+    import torch
+    hip = _hip_runtime()
+    scene = rt.build_scene(rt.SCENE_CLOUD, n=60000, seed=11)
+    r = rt.Renderer(0)
+    try:
+        r.upload(scene, rt.ACCEL_LBVH)
+        n = 150_000
+        o, d = _device_rays(torch, 901, n)
+        want = _outputs(torch, n)
+        r.trace_device(o.data_ptr(), d.data_ptr(), n, want[0].data_ptr(), want[1].data_ptr(), want[2].data_ptr())
+        r.synchronize()
+        got = _outputs(torch, n)
+        torch.cuda.synchronize()
+        stream = ctypes.c_void_p(r.stream())
+        graph, graph_exec = ctypes.c_void_p(), ctypes.c_void_p()
+        assert hip.hipStreamBeginCapture(stream, 2) == 0        # hipStreamCaptureModeRelaxed
+        try:
+            r.trace_noalloc(o.data_ptr(), d.data_ptr(), n, got[0].data_ptr(), got[1].data_ptr(), got[2].data_ptr())
+        finally:
+            rc = hip.hipStreamEndCapture(stream, ctypes.byref(graph))
+        assert rc == 0 and graph.value, f"capture ended with {rc}"
+        with pytest.raises(rt.RtError):     # no timing events were recorded into the graph
+            r.last_kernel_ms()
+        assert torch.equal(got[0], torch.full_like(got[0], -7)), "capturing must not run anything"
+        assert hip.hipGraphInstantiate(ctypes.byref(graph_exec), graph, None, None, ctypes.c_size_t(0)) == 0
+        for _ in range(2):
+            for g in got:
+                g.fill_(-7)
+            torch.cuda.synchronize()
+            assert hip.hipGraphLaunch(graph_exec, stream) == 0
+            r.synchronize()
+            assert torch.equal(got[0], want[0]) and _same(got[1], want[1]) and _same(got[2], want[2])
+        assert hip.hipGraphExecDestroy(graph_exec) == 0 and hip.hipGraphDestroy(graph) == 0
+        # an uncaptured call afterwards is timed again
+        r.trace_noalloc(o.data_ptr(), d.data_ptr(), n, got[0].data_ptr(), got[1].data_ptr(), got[2].data_ptr())
+        r.synchronize()
+        assert r.last_kernel_ms()[0] > 0.0
+    finally:
+        r.close()

@@ -7,6 +7,5 @@ from raytrace_amd import build
 name, flags = sys.argv[1], sys.argv[2:]
 out = os.path.join(build.ROOT, "variants", name + ".so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-subprocess.check_call([build.HIPCC] + build.HIP_FLAGS + flags + ["-o", out, os.path.join(build.CSRC, "rt_api.hip"),
-                       os.path.join(build.CSRC, "rt_gl_capture.cpp")])
+build.build_device(force=True, extra_flags=flags, out=out, objdir=os.path.join(build.ROOT, "variants", "obj_" + name))
 print(out)

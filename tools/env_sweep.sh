@@ -3,7 +3,7 @@
 name=$1; vals=$2; shift 2
 mkdir -p gpurun_out/sweep
 for v in $vals; do
-  env $name=$v timeout -k 10 200 python3 bench.py "$@" --no-cpu-baseline > gpurun_out/sweep/${name}_$v.json 2> gpurun_out/sweep/${name}_$v.err || { echo "$name=$v failed"; tail -3 gpurun_out/sweep/${name}_$v.err; exit 1; }
+  env RT_TUNING=1 $name=$v timeout -k 10 200 python3 bench.py "$@" --no-cpu-baseline > gpurun_out/sweep/${name}_$v.json 2> gpurun_out/sweep/${name}_$v.err || { echo "$name=$v failed"; tail -3 gpurun_out/sweep/${name}_$v.err; exit 1; }
   python3 - gpurun_out/sweep/${name}_$v.json $name $v <<'PY'
 import json, sys
 j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

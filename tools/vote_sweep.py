@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run the C2 render at reduced spp for one RT_PHASE_VOTE value (env) and print time + SIMD occupancy counters."""
+"""Run the C2 render at reduced spp for one RT_PHASE_VOTE value (environment, with RT_TUNING=1) and print time + SIMD occupancy counters."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytrace_amd as rt
