@@ -13,7 +13,8 @@ import numpy as np
 from raytrace_amd._lib import RtCounters, RtParams
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "librt_oracle.so")
+# RT_ORACLE_LIB names another build of the checker (the sanitizer build of `make -C oracle ubsan`).
+LIB = os.environ.get("RT_ORACLE_LIB") or os.path.join(HERE, "librt_oracle.so")
 _lib = None
 
 

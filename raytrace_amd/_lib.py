@@ -12,7 +12,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # RAYTRACE_AMD_LIB names another build of the same library (kernel tuning experiments).
 DEVICE_LIB = os.environ.get("RAYTRACE_AMD_LIB") or os.path.join(HERE, "libraytrace_amd.so")
-HOST_LIB = os.path.join(HERE, "librt_host.so")
+# RAYTRACE_AMD_HOST_LIB names another build of the host harness (the sanitizer build of `make -C oracle ubsan`).
+HOST_LIB = os.environ.get("RAYTRACE_AMD_HOST_LIB") or os.path.join(HERE, "librt_host.so")
 
 c_float3 = ctypes.c_float * 3
 

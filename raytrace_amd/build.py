@@ -68,6 +68,18 @@ def build_device(force=False, extra_flags=(), out=None, objdir=None, jobs=None):
     return out
 
 
+def kernel_sources_sha():
+    """SHA-256 over the device library's sources (csrc/, include/*.h), in name order: what a committed profile of the
+    kernels was taken at.  bench.py replays counter figures from profiles/ only when this still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in _glob(CSRC, (".hip", ".cuh", ".hpp", ".cpp")) + _glob(os.path.join(ROOT, "include"), (".h",)):
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def build_host(force=False):
     out = os.path.join(HERE, "librt_host.so")
     srcs = [os.path.join(HOST, "rt_host.cpp"), os.path.join(CSRC, "rt_gl_capture.cpp")]
@@ -89,5 +101,14 @@ def build_all(force=False):
     build_oracle()
 
 
+def build_sanitized():
+    """The host-side C++ under AddressSanitizer + UndefinedBehaviorSanitizer (oracle/Makefile: asan runs its driver, ubsan
+    builds the two libraries the Python CPU tests can load)."""
+    _run(["make", "-C", os.path.join(ROOT, "oracle"), "asan", "ubsan"])
+
+
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv)
+    if "--asan" in sys.argv:
+        build_sanitized()
+    else:
+        build_all(force="--force" in sys.argv)

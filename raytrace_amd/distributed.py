@@ -6,6 +6,10 @@ sample's random stream depends on (seed, pixel, sample) only, so the image does 
 is one collective on the accumulator tensor: `torch.distributed.reduce` to the root, which on ROCm's "nccl"
 backend is RCCL over xGMI (the root receives world-1 partial images over its point-to-point links; nobody else
 needs the result, so no all-reduce).
+
+State of the evidence: on hardware the device-ordered exchange (events between the library's stream and the
+collective's, the cached send / receive buffers of gather_rows, the in-place reduce) has run with ONE rank only; with two
+and three ranks it has run through gloo on the CPU and on ranks sharing one GPU (tests/test_distributed.py).
 """
 from dataclasses import dataclass
 
@@ -138,6 +142,11 @@ def gather_rows(accum, shares, rank: int, dst: int = 0, group=None, after=None):
     import torch
     import torch.distributed as dist
     world = len(shares)
+    # a list that does not match the group would leave some rank waiting in the collective for ever: fail here instead
+    if world != dist.get_world_size(group):
+        raise ValueError(f"gather_rows: {world} shares for a group of {dist.get_world_size(group)} ranks")
+    if rank != dist.get_rank(group):
+        raise ValueError(f"gather_rows: called as rank {rank} by rank {dist.get_rank(group)} of the group")
     if any((s.s0, s.s1) != (shares[0].s0, shares[0].s1) for s in shares):
         raise ValueError("gather_rows needs shares that differ in rows only")
     device_ordered = accum.is_cuda and dist.get_backend(group) == "nccl"

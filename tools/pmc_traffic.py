@@ -86,7 +86,9 @@ def main():
         commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=os.path.dirname(os.path.abspath(__file__))).decode().strip()
     except Exception:
         commit = "?"
-    out["_meta"] = {"date": datetime.date.today().isoformat(), "commit": commit,
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from raytrace_amd.build import kernel_sources_sha
+    out["_meta"] = {"date": datetime.date.today().isoformat(), "commit": commit, "kernel_sources_sha": kernel_sources_sha(),
                     "command": "tools/profile_round.sh (rocprofv3 --pmc passes of bench.py --steps 1 --warmup 0 --no-extras --no-cpu-baseline)"}
     print(json.dumps(out, indent=1))
 
