@@ -81,8 +81,9 @@ def test_interleaved_strips_compose_bit_for_bit(renderer, accel, size, spp, worl
 @pytest.mark.gpu
 def test_c5_frame_from_the_shares_of_eight_ranks(renderer):
     """3840x2160 (the 8-GPU configuration's frame) at 64 samples per pixel: the shares of split_frame(2160, S, 8, 2)
-    — two row bands x four sample ranges — and of eight interleaved strip sets, each rendered into one accumulator,
-    against the one-call frame; and the tree against the scan on the same frame."""
+    — two row bands x four sample ranges — of eight interleaved strip sets, and of four strip sets x two sample ranges
+    (what bench.py --config c5 gives eight ranks), each rendered into one accumulator, against the one-call frame; and
+    the tree against the scan on the same frame."""
     scene = rt.build_scene(rt.SCENE_RANDOM_SPHERES)
     W, H, S = 3840, 2160, 64
     p = rt.make_params(rt.scene_camera(rt.SCENE_RANDOM_SPHERES), W, H, S, rng_mode=rt.RNG_COUNTER)
@@ -95,7 +96,20 @@ def test_c5_frame_from_the_shares_of_eight_ranks(renderer):
     # goes on from the accumulator exactly as in one call
     banded = _shares(renderer, p, rtd.split_frame(H, S, 8, 2))
     assert np.array_equal(_bits(banded), _bits(whole)), "row bands x sample ranges in order"
+    # the shares bench.py gives eight ranks of this configuration: four interleaved strip sets x two sample ranges (in
+    # rank order the first range of every strip set comes before the second, so the sums go on in sample order)
+    mixed = _shares(renderer, p, rtd.split_interleaved(H, S, 8, sample_groups=2))
+    assert np.array_equal(_bits(mixed), _bits(whole)), "interleaved strips x sample ranges in order"
     # what an RCCL sum of separate per-rank accumulators gives: the same samples added in another order
+    for shares in (rtd.split_interleaved(H, S, 8, sample_groups=2),):
+        total = np.zeros_like(whole, dtype=np.float64)
+        for sh in shares:
+            renderer.clear()
+            renderer.render(rtd.apply_share(p, sh))
+            renderer.set_accumulated_samples(S)
+            total += renderer.readback(rgb8=False)[0].astype(np.float32)
+        ok = np.isfinite(whole)
+        np.testing.assert_allclose(total.astype(np.float32)[ok], whole[ok], rtol=2e-5, atol=1e-6)
     total = np.zeros_like(whole, dtype=np.float64)
     for sh in rtd.split_frame(H, S, 8, 2):
         renderer.clear()
