@@ -17,7 +17,8 @@ struct render_args {
   unsigned long long* counters;  // sizeof(rt_counters)/8 words, or null
   unsigned int* queue;         // head of the pixel queue, zero at launch
   int vote;                    // ready lanes needed before a wave leaves traversal for the path phase
-  int leaf_vote;               // lanes with queued leaves needed before a wave takes a leaf step
+  int leaf_vote;               // lanes with queued leaves needed before a wave takes a leaf step (trees read from HBM)
+  int batch_vote;              // nodes with waiting leaves a wave meets before it makes their tests together (trees in LDS)
   // Two-pass rendering (pixel queue ordered by measured cost):
   //   pass 0  everything in one launch, queue in tile order
   //   pass 1  probe: the first few samples of every pixel in tile order; leaves the pixel's
@@ -232,18 +233,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       const unsigned long long m_trav = __ballot(srch.active());
       if (m_trav == 0ull || __popcll(m_live & ~m_trav) >= A.vote) break;
       RT_CLK_START();
-      const bool node_lane = srch.node_ready(), leaf_lane = srch.has_leaf();
-      if (srch.leaf_steps && (__ballot(node_lane) == 0ull || __popcll(__ballot(leaf_lane)) >= A.leaf_vote)) {
-        RT_COUNT(k, leaf_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
-        RT_COUNT(k, leaf_lane_steps, leaf_lane ? 1u : 0u);
-        if (leaf_lane) srch.step_leaf(sc, sv, stack_col, k);
-      } else {
-        RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
-        RT_COUNT(k, trav_lane_steps, node_lane ? 1u : 0u);
-        uint32_t staged = 0u;  // the whole wave fetches the nodes its lanes want
-        if (search_traits<SEARCH>::staged) staged = stage_nodes(sv.qnodes, node_lane ? srch.node_wanted() : -1, stage);
-        if (node_lane) srch.step_node(sv, stack_col, staged, k);
-      }
+      traversal_action(srch, sc, sv, stack_col, stage, A.leaf_vote, A.batch_vote, k);
       RT_CLK_STOP(0);
     }
     RT_CLK_START();
@@ -443,18 +433,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
     while (search_traits<SEARCH>::tree) {
       const unsigned long long m_trav = __ballot(srch.active());
       if (m_trav == 0ull || __popcll(m_live & ~m_trav) >= A.vote) break;
-      const bool node_lane = srch.node_ready(), leaf_lane = srch.has_leaf();
-      if (srch.leaf_steps && (__ballot(node_lane) == 0ull || __popcll(__ballot(leaf_lane)) >= A.leaf_vote)) {
-        RT_COUNT(k, leaf_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
-        RT_COUNT(k, leaf_lane_steps, leaf_lane ? 1u : 0u);
-        if (leaf_lane) srch.step_leaf(sc, sv, stack_col, k);
-      } else {
-        RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
-        RT_COUNT(k, trav_lane_steps, node_lane ? 1u : 0u);
-        uint32_t staged = 0u;
-        if (search_traits<SEARCH>::staged) staged = stage_nodes(sv.qnodes, node_lane ? srch.node_wanted() : -1, stage);
-        if (node_lane) srch.step_node(sv, stack_col, staged, k);
-      }
+      traversal_action(srch, sc, sv, stack_col, stage, A.leaf_vote, A.batch_vote, k);
     }
     RT_COUNT(k, path_wave_phases, (threadIdx.x & 63) == 0 ? 1u : 0u);
     const bool ready = !srch.active() && none(DONE);

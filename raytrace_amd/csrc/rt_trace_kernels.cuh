@@ -16,6 +16,7 @@ struct trace_args {
   unsigned long long* queue;  // next ray index, zero at launch
   int vote;
   int leaf_vote;
+  int batch_vote;
 };
 
 // hit_any (fs:165-199) for a batch of rays: persistent lanes pull ray indices
@@ -42,18 +43,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
     while (search_traits<SEARCH>::tree) {
       const unsigned long long m_trav = __ballot(srch.active());
       if (m_trav == 0ull || __popcll(m_live & ~m_trav) >= A.vote) break;
-      const bool node_lane = srch.node_ready(), leaf_lane = srch.has_leaf();
-      if (srch.leaf_steps && (__ballot(node_lane) == 0ull || __popcll(__ballot(leaf_lane)) >= A.leaf_vote)) {
-        RT_COUNT(k, leaf_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
-        RT_COUNT(k, leaf_lane_steps, leaf_lane ? 1u : 0u);
-        if (leaf_lane) srch.step_leaf(sc, sv, stack_col, k);
-      } else {
-        RT_COUNT(k, trav_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
-        RT_COUNT(k, trav_lane_steps, node_lane ? 1u : 0u);
-        uint32_t staged = 0u;  // the whole wave fetches the nodes its lanes want
-        if (search_traits<SEARCH>::staged) staged = stage_nodes(sv.qnodes, node_lane ? srch.node_wanted() : -1, stage);
-        if (node_lane) srch.step_node(sv, stack_col, staged, k);
-      }
+      traversal_action(srch, sc, sv, stack_col, stage, A.leaf_vote, A.batch_vote, k);
     }
     RT_COUNT(k, path_wave_phases, (threadIdx.x & 63) == 0 ? 1u : 0u);
     const bool ready = !(srch.active() || exhausted);
