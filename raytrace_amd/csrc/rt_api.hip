@@ -283,7 +283,6 @@ int rt_trace_batch_device(rt_ctx* c, const float* o_xyz, const float* d_xyz, siz
   a.queue = c->queue.p;
   a.vote = trace_vote();
   a.leaf_vote = leaf_vote();
-  a.batch_vote = batch_vote();
   if (counted) {
     HIP_TRY(c->counters.resize(sizeof(rt_counters) / sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(rt_counters), c->stream));
@@ -329,7 +328,6 @@ int rt_trace_batch_noalloc(rt_ctx* c, const float* o_xyz, const float* d_xyz, si
   a.queue = reinterpret_cast<unsigned long long*>(scratch);
   a.vote = trace_vote();
   a.leaf_vote = leaf_vote();
-  a.batch_vote = batch_vote();
   unsigned char* ovf = scratch + kNoAllocHeaderBytes;
   const size_t ovf_bytes = (size_t)RT_NOALLOC_SCRATCH_BYTES - kNoAllocHeaderBytes;
   hipError_t e;

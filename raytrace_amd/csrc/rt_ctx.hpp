@@ -300,11 +300,6 @@ inline int trace_vote() {
   return v;
 }
 // Lanes with queued leaves a wave waits for before it takes a leaf step.
-// Nodes with waiting leaves a wave meets before it makes their exact tests together (trees in LDS).
-inline int batch_vote() {
-  static int v = vote_from_env("RT_BATCH_VOTE", RT_BATCH_VOTE);
-  return v;
-}
 inline int leaf_vote() {
   static int v = vote_from_env("RT_LEAF_VOTE", RT_LEAF_VOTE);
   return v;

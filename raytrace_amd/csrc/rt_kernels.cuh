@@ -49,9 +49,7 @@ struct search_traits {
   // per wave: one word per entry and lane; above the last row, three rows of slack for trees in LDS (a node step
   // stores three keys above the top whatever it pushes), one row for the others (the sink of stores that do not fit)
   // (trees read from HBM: above the sink row, the rows of the lane's leaf queue)
-  // (trees in LDS whose leaf tests a wave makes together: above the slack, the rows of tree_search::leaf_phase)
-  static constexpr bool batch = lds && RT_LDS_LEAF_BATCH && !RT_LDS_LEAF_STEPS;
-  static constexpr int stack_words = !tree ? 0 : (stack + (lds ? 3 + (batch ? RT_LEAF_BATCH_ROWS : 0) : 1 + RT_LEAF_ROWS)) * 64;
+  static constexpr int stack_words = !tree ? 0 : (stack + (lds ? 3 : 1 + RT_LEAF_ROWS)) * 64;
   // trees read from HBM pass their nodes through a per-wave staging area in LDS (stage_nodes)
   static constexpr bool staged = tree && !lds;
   static constexpr int stage_bytes = staged ? RT_STAGE_BYTES : 0;
@@ -195,12 +193,9 @@ struct searcher {
     return false;
   }
   static constexpr bool leaf_steps = T::tree && (!T::lds || RT_LDS_LEAF_STEPS);  // leaves wait for a step of their own
-  int wave_waiting;  // T::batch: nodes with leaves that wait in this wave since its last leaf phase (the same in every lane)
   RT_DEV void reset() {  // no search under way
     ts.cur = -1;
-    wave_waiting = 0;
-    if (ts.LEAF_BATCH) ts.nq = 0ull;
-    else if (!ts.LEAF_INLINE) ts.lq.clear();
+    if (!ts.LEAF_INLINE) ts.lq.clear();
   }
   RT_DEV bool node_ready() const { return T::tree && ts.node_ready(); }
   RT_DEV bool has_leaf() const { return T::tree && ts.has_leaf(); }
@@ -214,11 +209,6 @@ struct searcher {
   RT_DEV int node_wanted() const { return ts.cur; }
   RT_DEV void step_leaf(const scene_dev& sc, const scene_view& sv, const uint32_t* stack_col, lane_counters& k) {
     ts.step_leaf(sc, sv, stack_col + (T::stack + 1) * 64, k);
-  }
-  // T::batch: the wave's waiting leaf tests, made by all its lanes together (every lane calls this)
-  RT_DEV void leaf_phase(const scene_view& sv, uint32_t* stack_col, lane_counters& k) {
-    uint32_t* area = stack_col - (threadIdx.x & 63) + (T::stack + 3) * 64;  // the wave's rows above its stack rows and their slack
-    wave_waiting = ts.leaf_phase(sv, area, k);
   }
   RT_DEV void finish(const scene_dev& sc, const scene_view& sv, float& t, int& idx, lane_counters& k) {
     if (!T::tree) {  // the scan is the search
@@ -236,27 +226,16 @@ struct searcher {
 #define RT_PHASE_VOTE 52
 #define RT_TRACE_VOTE 8
 #define RT_LEAF_VOTE 8
-#define RT_BATCH_VOTE 40
 
-// One traversal action of a wave, for the lanes whose search is under way: a node step, or — by vote — a step for
-// waiting leaves.  Every lane of the wave must call this together.
-//   trees read from HBM   leaves wait in the lane's queue; a leaf step (one leaf per lane) when `leaf_vote` lanes hold one
-//   trees in LDS          leaves wait as well, and once `batch_vote` nodes with leaves have been met by the wave — or no
-//                         lane can take a node step — the wave makes all waiting tests together (tree_search::leaf_phase)
+// One traversal action of a wave, for the lanes whose search is under way: a node step, or — trees read from HBM,
+// whose leaves wait in the lane's queue — a leaf step (one leaf per lane) once `leaf_vote` lanes hold one or no lane
+// can take a node step.  Every lane of the wave must call this together.
 template <int SEARCH, bool COUNTED>
 RT_DEV void traversal_action(searcher<SEARCH, COUNTED>& srch, const scene_dev& sc, const scene_view& sv, uint32_t* stack_col,
-                             uint32_t stage, int leaf_vote, int batch_vote, lane_counters& k) {
+                             uint32_t stage, int leaf_vote, lane_counters& k) {
   using T = search_traits<SEARCH>;
   const bool node_lane = srch.node_ready(), leaf_lane = srch.has_leaf();
-  const unsigned long long m_node = __ballot(node_lane);
-  if (T::batch) {
-    if (m_node == 0ull || srch.wave_waiting >= batch_vote) {
-      RT_COUNT(k, leaf_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
-      RT_COUNT(k, leaf_lane_steps, leaf_lane ? 1u : 0u);
-      srch.leaf_phase(sv, stack_col, k);
-      return;
-    }
-  } else if (srch.leaf_steps && (m_node == 0ull || __popcll(__ballot(leaf_lane)) >= leaf_vote)) {
+  if (srch.leaf_steps && (__ballot(node_lane) == 0ull || __popcll(__ballot(leaf_lane)) >= leaf_vote)) {
     RT_COUNT(k, leaf_wave_steps, (threadIdx.x & 63) == 0 ? 1u : 0u);
     RT_COUNT(k, leaf_lane_steps, leaf_lane ? 1u : 0u);
     if (leaf_lane) srch.step_leaf(sc, sv, stack_col, k);
@@ -266,12 +245,7 @@ RT_DEV void traversal_action(searcher<SEARCH, COUNTED>& srch, const scene_dev& s
   RT_COUNT(k, trav_lane_steps, node_lane ? 1u : 0u);
   uint32_t staged = 0u;  // trees read from HBM: the whole wave fetches the nodes its lanes want
   if (T::staged) staged = stage_nodes(sv.qnodes, node_lane ? srch.node_wanted() : -1, stage);
-  bool met_leaves = false;
-  if (node_lane) {
-    srch.step_node(sv, stack_col, staged, k);
-    met_leaves = T::batch && srch.ts.met_leaves;
-  }
-  if (T::batch) srch.wave_waiting += __popcll(__ballot(met_leaves));
+  if (node_lane) srch.step_node(sv, stack_col, staged, k);
 }
 
 // Work items (pixels, rays) come from one global counter.  Same-address atomics

@@ -219,7 +219,6 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   a.queue = reinterpret_cast<unsigned int*>(c->queue.p);
   a.vote = phase_vote();
   a.leaf_vote = leaf_vote();
-  a.batch_vote = batch_vote();
   if (p->rng_mode == RT_RNG_XORSHIFT_REF && p->seed_tex) {
     HIP_TRY(c->seed_tex.resize(n_px));
     HIP_TRY(hipMemcpyAsync(c->seed_tex.p, p->seed_tex, n_px * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));

@@ -17,8 +17,7 @@ struct render_args {
   unsigned long long* counters;  // sizeof(rt_counters)/8 words, or null
   unsigned int* queue;         // head of the pixel queue, zero at launch
   int vote;                    // ready lanes needed before a wave leaves traversal for the path phase
-  int leaf_vote;               // lanes with queued leaves needed before a wave takes a leaf step (trees read from HBM)
-  int batch_vote;              // nodes with waiting leaves a wave meets before it makes their tests together (trees in LDS)
+  int leaf_vote;               // lanes with queued leaves needed before a wave takes a leaf step
   // Two-pass rendering (pixel queue ordered by measured cost):
   //   pass 0  everything in one launch, queue in tile order
   //   pass 1  probe: the first few samples of every pixel in tile order; leaves the pixel's
@@ -233,7 +232,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
       const unsigned long long m_trav = __ballot(srch.active());
       if (m_trav == 0ull || __popcll(m_live & ~m_trav) >= A.vote) break;
       RT_CLK_START();
-      traversal_action(srch, sc, sv, stack_col, stage, A.leaf_vote, A.batch_vote, k);
+      traversal_action(srch, sc, sv, stack_col, stage, A.leaf_vote, k);
       RT_CLK_STOP(0);
     }
     RT_CLK_START();
@@ -433,7 +432,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
     while (search_traits<SEARCH>::tree) {
       const unsigned long long m_trav = __ballot(srch.active());
       if (m_trav == 0ull || __popcll(m_live & ~m_trav) >= A.vote) break;
-      traversal_action(srch, sc, sv, stack_col, stage, A.leaf_vote, A.batch_vote, k);
+      traversal_action(srch, sc, sv, stack_col, stage, A.leaf_vote, k);
     }
     RT_COUNT(k, path_wave_phases, (threadIdx.x & 63) == 0 ? 1u : 0u);
     const bool ready = !srch.active() && none(DONE);

@@ -468,10 +468,6 @@ RT_DEV float byte_of(uint32_t w, int ch) { return (float)((w >> (8 * ch)) & 255u
 #ifndef RT_LDS_LEAF_STEPS
 #define RT_LDS_LEAF_STEPS 0   // 1: trees in LDS queue their leaves for voted leaf steps too (tuning builds)
 #endif
-#ifndef RT_LDS_LEAF_BATCH
-#define RT_LDS_LEAF_BATCH 0   // 1 (tuning builds, with -DRT_LDS_STACK=10 for the room): trees in LDS let their leaf tests wait, and a wave makes them together, spread over all its lanes (leaf_phase); measured slower, see there
-#endif
-#define RT_LEAF_BATCH_ROWS 3  // per wave, above the stack rows: the list of waiting tests (one row) and the owners' result words (two)
 #ifndef RT_STAGE_PIECES
 #define RT_STAGE_PIECES 4
 #endif
@@ -606,50 +602,24 @@ RT_DEV int pick_ref(int4 ref, unsigned mask) {
 //   step_leaf()  exact test of one queued leaf
 //   active()     false when the search is over
 //   finish()     the scan's answer (repeats the ray with the scan when flagged)
-// Tuning builds (-DRT_CULL_DELAY=1..3, trees in LDS only): what the search would lose if a leaf test's result reached
-// the culling tests late — 1: not before the next node step (the step that found the leaf still descends as if it
-// had not), 2 / 3: one / two node steps later still.  The leaf tests themselves are made as always and the result
-// is unchanged; only box tests and stack pops look at a stale closest hit.
-#ifndef RT_CULL_DELAY
-#define RT_CULL_DELAY 0
-#endif
 template <bool PAD_RAY, bool PACKED, int STACK, bool COUNTED, bool QUADS = false>
 struct tree_search {
   f3 o, d;
   float a;
   slab_consts sl;
   trav_candidate c;
-  static constexpr int DELAY = PACKED ? RT_CULL_DELAY : 0;
-  trav_candidate cn, h1, h2;  // DELAY: the true closest hit, and what it was one and two steps ago
-  RT_DEV trav_candidate& live() { return DELAY ? cn : c; }
   int cur, sp;  // cur: node to test next, -1 when the stack has run dry
   int best_pos; // trees read from HBM: the closest hit's place in leaf_rec, -1 while it is none of the tree's spheres
-  static constexpr bool LEAF_BATCH = PACKED && RT_LDS_LEAF_BATCH && !RT_LDS_LEAF_STEPS;
-  static constexpr bool LEAF_INLINE = PACKED && !RT_LDS_LEAF_STEPS && !LEAF_BATCH;
+  static constexpr bool LEAF_INLINE = PACKED && !RT_LDS_LEAF_STEPS;
   static constexpr bool SELECT = PAD_RAY && PACKED;  // planes picked by direction sign (slab_consts)
   leaf_queue<PACKED> lq;
-  // LEAF_BATCH: the nodes whose leaf children wait for their exact tests, up to four of them, 16 bits each:
-  // node index << 4 | mask of the leaf children whose boxes the ray meets (zero: nothing waits)
-  unsigned long long nq;
-  bool met_leaves;  // ... and whether the last node step added one
 
   RT_DEV bool has_node() const { return cur >= 0; }
-  RT_DEV bool node_ready() const {
-    if (LEAF_BATCH) return cur >= 0 && (nq >> 48) == 0ull;  // room for one more node
-    return cur >= 0 && (LEAF_INLINE || lq.room_for_node());
-  }
-  RT_DEV bool has_leaf() const {
-    if (LEAF_BATCH) return (nq & 0x000F000F000F000Full) != 0ull;  // some node's mask names a leaf
-    return !LEAF_INLINE && !lq.empty();
-  }
+  RT_DEV bool node_ready() const { return cur >= 0 && (LEAF_INLINE || lq.room_for_node()); }
+  RT_DEV bool has_leaf() const { return !LEAF_INLINE && !lq.empty(); }
   RT_DEV bool active() const { return cur >= 0 || has_leaf(); }
 
   RT_DEV bool begin(const scene_dev& sc, const scene_view& sv, f3 origin, f3 dir, lane_counters& k) {
-    const bool go = begin_search(sc, sv, origin, dir, k);
-    if (DELAY) cn = h1 = h2 = c;
-    return go;
-  }
-  RT_DEV bool begin_search(const scene_dev& sc, const scene_view& sv, f3 origin, f3 dir, lane_counters& k) {
     o = origin;
     d = dir;
     a = dot3(d, d);
@@ -658,8 +628,7 @@ struct tree_search {
     sp = 0;
     cur = -1;
     best_pos = -1;
-    if (LEAF_BATCH) nq = 0ull;
-    else if (!LEAF_INLINE) lq.clear();
+    if (!LEAF_INLINE) lq.clear();
     if (!(a > 0.0f) || !(a < __builtin_inff())) {  // zero, NaN or overflowing direction: the scan decides
       c.give_up();
       return false;
@@ -721,10 +690,6 @@ struct tree_search {
   // `staged`: where stage_nodes() put this lane's node (trees read from HBM; unused when the
   // whole tree is in LDS).
   RT_DEV void step_node(const scene_view& sv, trav_stack<PACKED> stk, uint32_t staged, lane_counters& k) {
-    const trav_candidate at_top = cn;
-    if (DELAY == 1) c = cn;
-    if (DELAY == 2) c = h1;
-    if (DELAY == 3) c = h2;
     const unsigned char* nd = rt_lds + staged;
     if (PACKED) nd = reinterpret_cast<const unsigned char*>(sv.nodes) + __umul24((unsigned)cur, (unsigned)RT_LDS_NODE_STRIDE);  // (full-rate multiply)
     int4 ref;
@@ -818,7 +783,7 @@ struct tree_search {
       // the reference; min / max of the two parameters would undo the inversion)
       ok[ch] = SELECT ? tn[ch] <= tf[ch] : bool((tn[ch] <= tf[ch]) & (refs[ch] != RT_REF_EMPTY));
       RT_COUNT(k, node_tests, refs[ch] != RT_REF_EMPTY ? 1u : 0u);
-      if (LEAF_INLINE || LEAF_BATCH) {
+      if (LEAF_INLINE) {
         leaf_mask |= (ok[ch] & (refs[ch] < 0)) ? (1u << ch) : 0u;  // a select on combined lane masks, not a branch per child
       } else {
         lq.push_if(stk.col + (STACK + 1) * 64, ok[ch] & (refs[ch] < 0), ~refs[ch]);
@@ -865,7 +830,6 @@ struct tree_search {
       sp += (int)pushed;
       if (sp > STACK) {  // (rare: a chain deeper than the rows)
         c.give_up();
-        if (DELAY) cn.give_up();
         sp = 0;
         key[0] = key[1] = key[2] = key[3] = 0u;
       }
@@ -886,22 +850,13 @@ struct tree_search {
     next = key[1] ? key[1] : next;
     next = key[2] ? key[2] : next;
     next = key[3] ? key[3] : next;
-    if (DELAY) {
-      h2 = h1;
-      h1 = at_top;
-    }
-    if (LEAF_BATCH) {  // the node joins the lane's waiting list (node_ready() saw to it that there is room)
-      const unsigned long long grown = (nq << 16) | (unsigned long long)(((uint32_t)cur << 4) | leaf_mask);
-      nq = leaf_mask ? grown : nq;
-      met_leaves = leaf_mask != 0u;
-    }
     if (LEAF_INLINE && leaf_mask) {
-      consider_sphere<COUNTED>(sph0, sv.leaf_idx[pos0], o, d, a, live(), k);
+      consider_sphere<COUNTED>(sph0, sv.leaf_idx[pos0], o, d, a, c, k);
       leaf_mask &= leaf_mask - 1;
       while (leaf_mask) {
         const int pos = ~leaf_ref(leaf_mask);
         leaf_mask &= leaf_mask - 1;
-        consider_sphere<COUNTED>(sv.leaf_sph[pos], sv.leaf_idx[pos], o, d, a, live(), k);
+        consider_sphere<COUNTED>(sv.leaf_sph[pos], sv.leaf_idx[pos], o, d, a, c, k);
       }
       if (!(stk.key_tn(next) <= c.best_t)) next = 0u;  // a leaf hit nearer than the nearest child: the stack decides
     }
@@ -927,95 +882,7 @@ struct tree_search {
     }
   }
 
-  // LEAF_BATCH: the exact tests of every leaf that waits in this wave, made by the wave as a whole.  A node step finds a
-  // leaf worth testing in one lane out of five, so tests made where they are found run on a sixth of the lanes; here
-  // they wait (a stale closest hit costs a few box tests: measured 3 % per step of delay) until the wave holds enough
-  // of them, are listed in LDS, and lane j makes test j whichever lane the ray belongs to: it fetches that lane's ray
-  // by ds_bpermute and returns t and the upload index through a 64-bit LDS minimum on the owner's word, which keeps the
-  // scan's rule — nearest hit, ties to the lower upload index — whatever the order of the tests.  A result the pruned
-  // search cannot use (NaN, a root of exactly 0.001) is the word 0, below every hit: the owner hands the ray to the scan.
-  // Measured on the 487-sphere frame (1920x1080x256): bit-identical frames, 38.7 instead of 34.3 lanes per vector
-  // instruction, but 59.3 - 62 ms against 51.8 at every vote from 4 to 40 nodes: a lane whose stack has run dry cannot
-  // shade before its last leaf is tested, so it idles until the wave's next phase (node steps fall from 52 to 42 - 49
-  // lanes, 11 - 33 % more of them), and a phase of 37 - 47 tests costs over 200 instructions where the tests made on
-  // the spot cost 95 per node step: 39.7 G vector instructions per frame against 36.1 G.  Kept as a tuning build.
-  // Every lane of the wave must call this together.  `area`: the wave's RT_LEAF_BATCH_ROWS rows of LDS.
-  // Returns how many of the wave's lanes still hold waiting tests (more than one list's worth waited).
-  RT_DEV int leaf_phase(const scene_view& sv, uint32_t* area, lane_counters& k) {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t* list = area;
-    unsigned long long* result = reinterpret_cast<unsigned long long*>(area + 64);
-    const uint32_t lo = (uint32_t)nq, hi = (uint32_t)(nq >> 32);
-    // bit 4 e + ch: leaf child ch of waiting node e
-    uint32_t waiting = (lo & 15u) | ((lo >> 12) & 0xF0u) | ((hi & 15u) << 8) | ((hi >> 4) & 0xF000u);
-    const bool owner = waiting != 0u;
-    unsigned long long mine = ~0ull;
-    if (c.best_i >= 0) mine = ((unsigned long long)__float_as_uint(c.best_t) << 32) | (unsigned long long)(uint32_t)c.best_i;
-    if (c.redo()) mine = 0ull;
-    result[lane] = mine;
-    uint32_t listed = 0;  // wave-uniform
-    while (true) {
-      const unsigned long long m = __ballot(waiting != 0u);
-      if (m == 0ull || listed >= 64u) break;
-      const uint32_t at = listed + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      if (waiting != 0u && at < 64u) {
-        const uint32_t bit = (uint32_t)__builtin_ctz(waiting);
-        waiting &= waiting - 1u;
-        const uint32_t node = ((uint32_t)(nq >> ((bit >> 2) * 16u)) >> 4) & 0xFFFu;
-        list[at] = (lane << 16) | (node << 2) | (bit & 3u);
-      }
-      listed += (uint32_t)__popcll(m);
-    }
-    const uint32_t n_tests = listed < 64u ? listed : 64u;
-    // (LDS operations of one wave execute in order; the fences keep the compiler from moving them across)
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // lane j makes test j: the ray comes from its owner's registers (every lane of the wave takes part in the exchange)
-    const uint32_t entry = lane < n_tests ? list[lane] : (lane << 16);
-    const int from = (int)((entry >> 16) << 2);
-    const f3 ro = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(o.x))),
-                      __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(o.y))),
-                      __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(o.z))));
-    const f3 rd = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(d.x))),
-                      __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(d.y))),
-                      __int_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_int(d.z))));
-    if (lane < n_tests) {
-      const unsigned char* nd = reinterpret_cast<const unsigned char*>(sv.nodes) + __umul24((entry >> 2) & 0xFFFu, (unsigned)RT_LDS_NODE_STRIDE);
-      const int pos = ~reinterpret_cast<const int32_t*>(nd + 96)[entry & 3u];
-      const float4 s = sv.leaf_sph[pos];
-      const uint32_t upload_index = (uint32_t)sv.leaf_idx[pos];
-      RT_COUNT(k, sphere_tests, 1);
-      const float ra = dot3(rd, rd);
-      float h, disc;
-      sphere_disc(s.x, s.y, s.z, s.w, ro, rd, ra, h, disc);
-      if (disc >= 0.0f) {
-        const float t = sphere_roots<COUNTED>(h, disc, ra, k);
-        unsigned long long word = ~0ull;
-        if (t > 0.001f) word = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)upload_index;
-        if (t != t || t == 0.001f) word = 0ull;
-        if (word != ~0ull) atomicMin(result + (entry >> 16), word);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (owner) {
-      const unsigned long long r = result[lane];
-      if (r == 0ull) {
-        c.give_up();
-      } else if (r != ~0ull) {
-        c.best_t = __uint_as_float((uint32_t)(r >> 32));
-        c.best_i = (int)(uint32_t)r;
-      }
-      // what did not fit the list keeps waiting: the nodes' masks are what is left of `waiting`
-      const uint32_t lo2 = (lo & 0xFFF0FFF0u) | (waiting & 15u) | ((waiting & 0xF0u) << 12);
-      const uint32_t hi2 = (hi & 0xFFF0FFF0u) | ((waiting >> 8) & 15u) | ((waiting & 0xF000u) << 4);
-      nq = waiting ? (((unsigned long long)hi2 << 32) | lo2) : 0ull;
-    }
-    return __popcll(__ballot(has_leaf()));
-  }
-
   RT_DEV void finish(const scene_dev& sc, const scene_view& sv, float& t_out, int& i_out, lane_counters& k) {
-    if (DELAY) c = cn;
     if (c.redo()) {
       best_pos = -1;
       hit_linear_lean<COUNTED>(sv.scan_sph, sc.n_spheres, o, d, t_out, i_out, k);

@@ -16,7 +16,6 @@ struct trace_args {
   unsigned long long* queue;  // next ray index, zero at launch
   int vote;
   int leaf_vote;
-  int batch_vote;
 };
 
 // hit_any (fs:165-199) for a batch of rays: persistent lanes pull ray indices
@@ -43,7 +42,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
     while (search_traits<SEARCH>::tree) {
       const unsigned long long m_trav = __ballot(srch.active());
       if (m_trav == 0ull || __popcll(m_live & ~m_trav) >= A.vote) break;
-      traversal_action(srch, sc, sv, stack_col, stage, A.leaf_vote, A.batch_vote, k);
+      traversal_action(srch, sc, sv, stack_col, stage, A.leaf_vote, k);
     }
     RT_COUNT(k, path_wave_phases, (threadIdx.x & 63) == 0 ? 1u : 0u);
     const bool ready = !(srch.active() || exhausted);
