@@ -108,7 +108,7 @@ def parse_args():
     ap.add_argument("--collective", choices=["gather", "reduce"], default="gather",
                     help="strip shares (N > 1): gather each rank's rows onto rank 0, or sum whole accumulators")
     ap.add_argument("--sample-groups", type=int, default=0,
-                    help="c5 with N > 1: sample ranges per strip set (0: two from four ranks on, else one)")
+                    help="c5 with N > 1: sample ranges per strip set (0: chosen from a share's pixels per lane, see c5_sample_groups)")
     ap.add_argument("--no-extras", action="store_true", help="skip the linear-scan, c3, c4 and weak-scaling legs")
     return ap.parse_args()
 
@@ -229,10 +229,18 @@ def trace_workload(rt, torch, r, dev, args, cfg, rank, world, accel):
     return wl
 
 
-def c5_sample_groups(args, world):
+def c5_sample_groups(args, world, pixels, lanes):
+    """Sample ranges per strip set of a strong-scaling frame with very many samples.  A share's pixels per lane decide:
+    up to 6 the library renders the share in chunks of samples with every sample stored, from about 12 on its lanes
+    sum whole pixels in registers, and both schedules keep the lanes busy (tools/share_rate.py --config c5: within
+    3 % of the whole job / N).  A share in between balances badly, so ranks pair up on larger strip sets and halve the
+    samples instead: c5 on four ranks (8 pixels per lane each) runs as 2 strip sets x 2 sample ranges."""
     if args.sample_groups > 0:
         return args.sample_groups
-    return 2 if world >= 4 and world % 2 == 0 else 1
+    g = 1
+    while world % (2 * g) == 0 and 6 * lanes < pixels * g // world < 12 * lanes:
+        g *= 2
+    return g
 
 
 def render_workload(rt, torch, dist, r, dev, args, cfg, rank, world, accel, sid, overrides=True):
@@ -250,7 +258,8 @@ def render_workload(rt, torch, dist, r, dev, args, cfg, rank, world, accel, sid,
     wl.keep = (accum,)
     wl.scene, wl.cam, wl.cfg = scene, cam, cfg
     strong = args.scaling == "strong" or bool(cfg.get("strong"))
-    groups = c5_sample_groups(args, world) if cfg.get("strong") else 1
+    lanes = torch.cuda.get_device_properties(dev).multi_processor_count * 1024 if dev.type == "cuda" else 256 * 1024
+    groups = c5_sample_groups(args, world, w * h, lanes) if cfg.get("strong") else 1
 
     def shares_of(strongly):
         total = spp if strongly else spp * world

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void rt_plan_jobs_kernel(const uint32_t* order
 }
 
 // Pixels that were cut into several jobs: the samples are added in sample order onto the sum the
-// probe pass carried, exactly as one lane would have added them.
+// probe pass carried (carry_colour null: onto the pixel's sum in the image), exactly as one lane would have added them.
 __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order, const uint32_t* parts, uint32_t n_candidates,
                                                           const float* carry_colour, const float4* split_samples, int samples,
                                                           uint32_t n_rows, int tile_x0, int tile_y0, int tile_w, int width,
@@ -82,7 +82,10 @@ __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_candidates || (!all_rows && parts[i] <= 1u)) return;
   const uint32_t rect_pixel = order[i];
-  f3 colour = mk3(carry_colour[3 * (size_t)rect_pixel], carry_colour[3 * (size_t)rect_pixel + 1], carry_colour[3 * (size_t)rect_pixel + 2]);
+  const int x = tile_x0 + (int)(rect_pixel % (uint32_t)tile_w), y = real_row((int)(rect_pixel / (uint32_t)tile_w), tile_y0, strip_count, strip_index);
+  float* dst = accum + 3 * ((size_t)y * (size_t)width + (size_t)x);
+  const float* from = carry_colour ? carry_colour + 3 * (size_t)rect_pixel : dst;  // (no carried sums: the image's own)
+  f3 colour = mk3(from[0], from[1], from[2]);
   if (pairs) {  // consecutive threads read consecutive 32-byte pairs of a plane
     for (int s = 0; s < samples; s += 2) {
       const float4* q = split_samples + pair_slot((uint32_t)s, i, n_rows);
@@ -99,8 +102,6 @@ __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order
       colour = colour + mk3(v.x, v.y, v.z);
     }
   }
-  const int x = tile_x0 + (int)(rect_pixel % (uint32_t)tile_w), y = real_row((int)(rect_pixel / (uint32_t)tile_w), tile_y0, strip_count, strip_index);
-  float* dst = accum + 3 * ((size_t)y * (size_t)width + (size_t)x);
   dst[0] = colour.x;
   dst[1] = colour.y;
   dst[2] = colour.z;

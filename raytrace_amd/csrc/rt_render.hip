@@ -352,11 +352,9 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       // Plan the main pass: one job per pixel, except that the most expensive pixels are cut into
       // several sample ranges (counter RNG only: the reference's generator runs through a pixel's
       // samples and cannot start in the middle).
-      const int main_begin = p->sample_begin + n_probe, main_samples = p->sample_end - main_begin;
       const uint32_t n = (uint32_t)n_rect;
       // a job should be a small fraction (1 / split_fineness()) of a lane's fair share of the frame
       const uint32_t lanes = (uint32_t)c->n_cu * 1024u * (uint32_t)split_fineness();
-      size_t want = split_budget / (stored_samples(main_samples) * kSampleFloats * sizeof(float));
       // (only where rays walk a tree worth the name: the scan and a tree of a few spheres gain nothing from
       // neighbouring rays, and every sample stored and read back costs them 24 bytes of traffic — the two-sphere
       // noise scene ran 18 % slower with six jobs per pixel)
@@ -370,20 +368,32 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       const bool heavy = walks_tree || (scans && c->n_spheres >= 64);
       const size_t row_cap = split_rows() >= 0 ? (size_t)split_rows()
                                                 : (heavy || n_rect < (size_t)c->n_cu * 4096 ? n_rect : (size_t)65536);
-      uint32_t max_split = (uint32_t)(want > row_cap ? row_cap : want);
-      if (p->rng_mode != RT_RNG_COUNTER) max_split = 0;
-      // the store of the cut pixels' samples: when the device cannot give it, fewer pixels are cut, in the end none
-      while (max_split > 0 && c->split_samples.fit((size_t)max_split * stored_samples(main_samples) * kSampleFloats) != hipSuccess) max_split /= 2;
-      const int splittable = max_split > 0 ? 1 : 0;
-      // every pixel has a row in the store: the main pass too runs in the kernel with rays in reserve
-      const int all_rows = splittable && max_split >= n && stored_ok ? 1 : 0;
-      // ... whose records go out in pairs, as long as the store stays below 2^31 records (a slot number's top bit
-      // marks the record that waits); RT_SAMPLE_PAIRS=0: every record on its own (comparison)
-      static const bool pairs_enabled = [] {
-        const char* e = tuning_env("RT_SAMPLE_PAIRS");
+      // So many samples that the budget cannot give every pixel a row for all of them (3840x2160x4096: 540 GB): the
+      // range is rendered in chunks of samples, each with a row for every pixel, all in the order and from the costs the
+      // one probe found.  The sums continue from chunk to chunk in sample order, so the image is that of one pass.
+      // Only where a lane has few pixels: whole pixels as jobs balance badly there (an eighth of that frame, 4 pixels
+      // per lane: 386 ms in two chunks against 456 to 489 ms with rows for the 525 000 most expensive pixels only),
+      // while a lane with many pixels is better off summing them in registers than storing every sample (the whole
+      // frame, 32 per lane: 3.16 s against 3.50 s in sixteen chunks; at 8 per lane the two tie).
+      // RT_SAMPLE_CHUNKS=0: never (comparison).
+      static const bool chunks_enabled = [] {
+        const char* e = tuning_env("RT_SAMPLE_CHUNKS");
         return !(e && e[0] == '0');
       }();
-      const int pairs = all_rows && pairs_enabled && (unsigned long long)n * (unsigned long long)main_samples < (1ull << 31) ? 1 : 0;
+      constexpr size_t kRecordBytes = kSampleFloats * sizeof(float), kFewestChunkSamples = 64, kChunkPixelsPerLane = 6;
+      int chunk_len = n_samples;
+      if (walks_tree && stored_ok && split_rows() < 0 && chunks_enabled && n_rect <= kChunkPixelsPerLane * (size_t)c->n_cu * 1024) {
+        const size_t fit_samples = split_budget / (n_rect * kRecordBytes);
+        if (fit_samples < stored_samples(n_samples - n_probe)) {
+          // (whole pairs of records, and fewer than 2^31 records in the store: see `pairs` below)
+          const size_t cap = std::min(fit_samples, (size_t)(((1ull << 31) - 1ull) / n_rect)) & ~(size_t)1;
+          if (cap >= kFewestChunkSamples) {
+            const size_t chunks = ((size_t)n_samples + cap - 1) / cap;
+            chunk_len = (int)((((size_t)n_samples + chunks - 1) / chunks + 1) & ~(size_t)1);
+            if (c->split_samples.fit(n_rect * stored_samples(chunk_len) * kSampleFloats) != hipSuccess) chunk_len = n_samples;
+          }
+        }
+      }
       HIP_TRY(c->plan_parts.resize(n));
       HIP_TRY(c->plan_first.resize(n));
       HIP_TRY(c->plan_counts.resize(1));
@@ -395,41 +405,66 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       HIP_TRY(hipMemsetAsync(c->plan_total.p, 0, sizeof(unsigned long long), c->stream));
       const unsigned grid = (n + 255) / 256;
       rt_plan_cost_kernel<<<grid < 256 ? grid : 256, 256, 0, c->stream>>>(c->carry_cost.p, n, c->plan_total.p);
-      rt_plan_count_kernel<<<grid, 256, 0, c->stream>>>(c->carry_cost.p, c->order_idx.p, n, c->plan_total.p, lanes, max_split, main_samples,
-                                                       splittable, fewest, c->plan_parts.p);
       HIP_TRY(hipGetLastError());
-      HIP_TRY(rocprim::exclusive_scan(c->scan_temp.p, scan_bytes, c->plan_parts.p, c->plan_first.p, 0u, n, rocprim::plus<uint32_t>(),
-                                      c->stream));
-      rt_plan_jobs_kernel<<<grid, 256, 0, c->stream>>>(c->order_idx.p, c->plan_parts.p, c->plan_first.p, n, main_begin,
-                                                      p->sample_end, all_rows, pairs, c->plan_jobs.p, c->plan_counts.p);
-      HIP_TRY(hipGetLastError());
-      render_args mainp = probe;
-      mainp.pass = 2;
-      mainp.p.sample_begin = main_begin;
-      mainp.p.sample_end = p->sample_end;
-      mainp.jobs = c->plan_jobs.p;
-      mainp.n_jobs = c->plan_counts.p;
-      mainp.split_samples = reinterpret_cast<float4*>(c->split_samples.p);
-      mainp.main_samples = main_samples;
-      mainp.split_rows = n < max_split ? n : max_split;
-      mainp.pairs = pairs;
-      // Not every pixel has a row: the same kernel in the form whose lanes sum whole pixels in registers (counter
-      // generator; RT_OWNED_RESERVE=0 keeps the kernel without reserves, for comparison)
-      static const bool owned_enabled = [] {
-        const char* e = tuning_env("RT_OWNED_RESERVE");
-        return !(e && e[0] == '0');
-      }();
-      // (a slot number's top bit marks a whole pixel's sample there, and the pixel's number takes 29 bits)
-      const bool owned = !all_rows && stored_ok && owned_enabled && n_rect <= (size_t)RT_TAG_PIXEL &&
-                         (unsigned long long)mainp.split_rows * (unsigned long long)main_samples < (1ull << 31);
-      if (owned) mainp.pairs = 0;
-      e = all_rows ? launch_stored_pass(mainp) : (owned ? launch_stored_pass(mainp, true) : launch(mainp, p));
-      if (e == hipSuccess && splittable) {
-        const uint32_t cand = n < max_split ? n : max_split;
-        rt_sum_split_kernel<<<(cand + 255) / 256, 256, 0, c->stream>>>(c->order_idx.p, c->plan_parts.p, cand, c->carry_colour.p,
-                                                                      reinterpret_cast<const float4*>(c->split_samples.p), main_samples, cand, p->tile_x0, p->tile_y0,
-                                                                      tw, p->width, p->strip_count, p->strip_index, all_rows, pairs, c->accum());
-        e = hipGetLastError();
+      for (int chunk_begin = p->sample_begin; chunk_begin < p->sample_end && e == hipSuccess; chunk_begin += chunk_len) {
+        const bool first_chunk = chunk_begin == p->sample_begin;
+        const int main_begin = first_chunk ? p->sample_begin + n_probe : chunk_begin;
+        const int main_end = std::min(chunk_begin + chunk_len, p->sample_end), main_samples = main_end - main_begin;
+        const size_t want = split_budget / (stored_samples(main_samples) * kRecordBytes);
+        uint32_t max_split = (uint32_t)(want > row_cap ? row_cap : want);
+        if (p->rng_mode != RT_RNG_COUNTER) max_split = 0;
+        // the store of the cut pixels' samples: when the device cannot give it, fewer pixels are cut, in the end none
+        while (max_split > 0 && c->split_samples.fit((size_t)max_split * stored_samples(main_samples) * kSampleFloats) != hipSuccess) max_split /= 2;
+        const int splittable = max_split > 0 ? 1 : 0;
+        // every pixel has a row in the store: the main pass too runs in the kernel with rays in reserve
+        // (the kernel's slot numbers are 32-bit: a budget beyond 64 GiB must not make a store of more records)
+        const int all_rows = splittable && max_split >= n && stored_ok &&
+                             (unsigned long long)n * stored_samples(main_samples) <= 0xFFFFFFFFull ? 1 : 0;
+        if (chunk_len < n_samples && !all_rows) return fail(RT_ERR_DEVICE, "a chunk of %d samples has no row for every pixel", main_samples);
+        // ... whose records go out in pairs, as long as the store stays below 2^31 records (a slot number's top bit
+        // marks the record that waits); RT_SAMPLE_PAIRS=0: every record on its own (comparison)
+        static const bool pairs_enabled = [] {
+          const char* e = tuning_env("RT_SAMPLE_PAIRS");
+          return !(e && e[0] == '0');
+        }();
+        const int pairs = all_rows && pairs_enabled && (unsigned long long)n * (unsigned long long)main_samples < (1ull << 31) ? 1 : 0;
+        rt_plan_count_kernel<<<grid, 256, 0, c->stream>>>(c->carry_cost.p, c->order_idx.p, n, c->plan_total.p, lanes, max_split, main_samples,
+                                                         splittable, fewest, c->plan_parts.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(rocprim::exclusive_scan(c->scan_temp.p, scan_bytes, c->plan_parts.p, c->plan_first.p, 0u, n, rocprim::plus<uint32_t>(),
+                                        c->stream));
+        rt_plan_jobs_kernel<<<grid, 256, 0, c->stream>>>(c->order_idx.p, c->plan_parts.p, c->plan_first.p, n, main_begin,
+                                                        main_end, all_rows, pairs, c->plan_jobs.p, c->plan_counts.p);
+        HIP_TRY(hipGetLastError());
+        render_args mainp = probe;
+        mainp.pass = 2;
+        mainp.p.sample_begin = main_begin;
+        mainp.p.sample_end = main_end;
+        mainp.jobs = c->plan_jobs.p;
+        mainp.n_jobs = c->plan_counts.p;
+        mainp.split_samples = reinterpret_cast<float4*>(c->split_samples.p);
+        mainp.main_samples = main_samples;
+        mainp.split_rows = n < max_split ? n : max_split;
+        mainp.pairs = pairs;
+        // Not every pixel has a row: the same kernel in the form whose lanes sum whole pixels in registers (counter
+        // generator; RT_OWNED_RESERVE=0 keeps the kernel without reserves, for comparison)
+        static const bool owned_enabled = [] {
+          const char* e = tuning_env("RT_OWNED_RESERVE");
+          return !(e && e[0] == '0');
+        }();
+        // (a slot number's top bit marks a whole pixel's sample there, and the pixel's number takes 29 bits)
+        const bool owned = !all_rows && stored_ok && owned_enabled && n_rect <= (size_t)RT_TAG_PIXEL &&
+                           (unsigned long long)mainp.split_rows * (unsigned long long)main_samples < (1ull << 31);
+        if (owned) mainp.pairs = 0;
+        e = all_rows ? launch_stored_pass(mainp) : (owned ? launch_stored_pass(mainp, true) : launch(mainp, p));
+        if (e == hipSuccess && splittable) {
+          const uint32_t cand = n < max_split ? n : max_split;
+          // (the first chunk continues the probe's sums, a later one what the chunk before it left in the image)
+          rt_sum_split_kernel<<<(cand + 255) / 256, 256, 0, c->stream>>>(c->order_idx.p, c->plan_parts.p, cand, first_chunk ? c->carry_colour.p : nullptr,
+                                                                        reinterpret_cast<const float4*>(c->split_samples.p), main_samples, cand, p->tile_x0, p->tile_y0,
+                                                                        tw, p->width, p->strip_count, p->strip_index, all_rows, pairs, c->accum());
+          e = hipGetLastError();
+        }
       }
     }
   }

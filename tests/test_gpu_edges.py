@@ -244,6 +244,38 @@ def test_tiny_scratch_budgets_give_the_same_frame(renderer, split_mb, probe_mb):
         renderer.set_scratch_budget(0, 0)
 
 
+@pytest.mark.parametrize("strips", [0, 2])
+def test_sample_chunks_give_the_frame_of_one_pass(renderer, strips):
+    """A sample range too long for the store's budget to give every pixel a row is rendered in chunks of samples that
+    continue each other's sums: bit for bit the oracle's frame, whole and as one rank's strips."""
+    scene = rt.build_scene(rt.SCENE_RANDOM_SPHERES)
+    cam = rt.scene_camera(rt.SCENE_RANDOM_SPHERES)
+    w, h, spp = 256, 144, 200   # (the strips' half of it still has the 16 384 pixels two-pass rendering asks for)
+    p = rt.make_params(cam, w, h, spp, rng_mode=rt.RNG_COUNTER)
+    if strips:
+        p.strip_count, p.strip_index = strips, 1
+    acc, _ = oracle.render(scene, p, threads=8)
+    want = oracle.resolve(acc, spp)[0]
+    try:
+        renderer.upload(scene, rt.ACCEL_LBVH)
+        # rows of 72 samples for every pixel of the whole frame: chunks of 68 (whole), of 100 (the strips' half of it)
+        renderer.set_scratch_budget(w * h * 16 * 72, 0)
+        renderer.clear()
+        renderer.render(p, counted=True)
+        chunked = renderer.counters()
+        assert_same_f32(renderer.readback(rgb8=False)[0], want, "in chunks")
+        assert renderer.last_kernel_ms()[1] == "rt_render_stored_kernel<lbvh4,lds,pad_ray>"
+        renderer.set_scratch_budget(0, 0)
+        renderer.clear()
+        renderer.render(p, counted=True)
+        whole = renderer.counters()
+        assert_same_f32(renderer.readback(rgb8=False)[0], want, "one pass")
+        for k in ("paths", "segments", "hits"):
+            assert chunked[k] == whole[k], k
+    finally:
+        renderer.set_scratch_budget(0, 0)
+
+
 # ---- the kernels' square root ---------------------------------------------------------------------------------
 
 def test_short_square_root_is_the_correctly_rounded_one(renderer):

@@ -81,9 +81,10 @@ def test_interleaved_strips_compose_bit_for_bit(renderer, accel, size, spp, worl
 @pytest.mark.gpu
 def test_c5_frame_from_the_shares_of_eight_ranks(renderer):
     """3840x2160 (the 8-GPU configuration's frame) at 64 samples per pixel: the shares of split_frame(2160, S, 8, 2)
-    — two row bands x four sample ranges — of eight interleaved strip sets, and of four strip sets x two sample ranges
-    (what bench.py --config c5 gives eight ranks), each rendered into one accumulator, against the one-call frame; and
-    the tree against the scan on the same frame."""
+    — two row bands x four sample ranges — of eight interleaved strip sets (what bench.py --config c5 gives eight
+    ranks), and of four strip sets x two sample ranges (the kind of share it gives ranks whose strips alone would leave
+    a lane about eight pixels: four ranks run as 2 x 2), each rendered into one accumulator, against the one-call
+    frame; and the tree against the scan on the same frame."""
     scene = rt.build_scene(rt.SCENE_RANDOM_SPHERES)
     W, H, S = 3840, 2160, 64
     p = rt.make_params(rt.scene_camera(rt.SCENE_RANDOM_SPHERES), W, H, S, rng_mode=rt.RNG_COUNTER)
@@ -96,8 +97,8 @@ def test_c5_frame_from_the_shares_of_eight_ranks(renderer):
     # goes on from the accumulator exactly as in one call
     banded = _shares(renderer, p, rtd.split_frame(H, S, 8, 2))
     assert np.array_equal(_bits(banded), _bits(whole)), "row bands x sample ranges in order"
-    # the shares bench.py gives eight ranks of this configuration: four interleaved strip sets x two sample ranges (in
-    # rank order the first range of every strip set comes before the second, so the sums go on in sample order)
+    # strip sets x sample ranges: four interleaved strip sets x two sample ranges (in rank order the first range of
+    # every strip set comes before the second, so the sums go on in sample order)
     mixed = _shares(renderer, p, rtd.split_interleaved(H, S, 8, sample_groups=2))
     assert np.array_equal(_bits(mixed), _bits(whole)), "interleaved strips x sample ranges in order"
     # what an RCCL sum of separate per-rank accumulators gives: the same samples added in another order
@@ -131,7 +132,9 @@ def test_c5_frame_at_its_stated_count_strips_equal_one_call(renderer):
     """3840x2160 x 4096 spp (34 G paths, the 8-GPU configuration's whole job): at this count the per-sample store
     cannot hold every pixel's samples, so only the most expensive pixels are cut into jobs and the main pass runs in the
     form of the kernel whose lanes sum whole pixels in registers — a schedule no smaller frame reaches.  The eight
-    interleaved strip sets (each a frame of 270 rows, scheduled on its own) against the frame in one call."""
+    interleaved strip sets (each a frame of 270 rows, scheduled on its own: four pixels per lane, so each is rendered
+    in two chunks of 2048 samples with every sample stored, the second continuing the first's sums) against the frame
+    in one call."""
     scene = rt.build_scene(rt.SCENE_RANDOM_SPHERES)
     W, H, S = 3840, 2160, 4096
     p = rt.make_params(rt.scene_camera(rt.SCENE_RANDOM_SPHERES), W, H, S, rng_mode=rt.RNG_COUNTER)
