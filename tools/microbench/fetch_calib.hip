@@ -9,6 +9,8 @@
 //                       (stage_nodes: the closest-hit kernel's node fetch), with plain loads
 //   calib_gather64_cached   the same gathers over a 64 MiB table, which stays in the Infinity Cache (the closest-hit
 //                       kernel's tree does): the rate at which L2 misses are answered from there
+//   calib_gather128     groups of eight lanes read one 128-byte node (a whole line) each, chosen at random: what a tree
+//                       of 128-byte nodes would ask of the fabric (1 GiB table, and 64 MiB as calib_gather128_cached)
 //   calib_gather64_x4   four gathers per lane in flight (1 GiB table, and 64 MiB as calib_gather64_x4_cached)
 //   calib_gather64_lds  the same through loads that write LDS directly, as stage_nodes issues them
 //   calib_halfline      every workgroup reads the even 64-byte halves of a private 128 KiB region, then the odd halves:
@@ -65,6 +67,18 @@ __global__ __launch_bounds__(256) void calib_gather64(const float4* table, uint3
   for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < 4 * n_gathers; t += (size_t)gridDim.x * 256) {
     const uint32_t node = mix((uint32_t)(t >> 2) * 2654435761u + 12345u) & node_mask;
     const float4 v = table[(size_t)node * 4 + sub];
+    s += v.x + v.w;
+  }
+  if (s == 12345.678f) sink[0] = s;
+}
+
+// node_mask + 1 nodes of 128 bytes
+__global__ __launch_bounds__(256) void calib_gather128(const float4* table, uint32_t node_mask, size_t n_gathers, float* sink) {
+  float s = 0.0f;
+  const uint32_t sub = threadIdx.x & 7u;
+  for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < 8 * n_gathers; t += (size_t)gridDim.x * 256) {
+    const uint32_t node = mix((uint32_t)(t >> 3) * 2654435761u + 12345u) & node_mask;
+    const float4 v = table[(size_t)node * 8 + sub];
     s += v.x + v.w;
   }
   if (s == 12345.678f) sink[0] = s;
@@ -183,6 +197,8 @@ int main() {
   timed("calib_stream16", (double)bytes, [&] { calib_stream16<<<grid, 256>>>(buf, bytes / 16, sink); });
   timed("calib_pair32", (double)bytes, [&] { calib_pair32<<<grid, 256>>>(buf, bytes / 32, sink); });
   timed("calib_gather64", (double)n_gathers * 64.0, [&] { calib_gather64<<<grid, 256>>>(table, node_mask, n_gathers, sink); });
+  timed("calib_gather128", (double)n_gathers * 64.0, [&] { calib_gather128<<<grid, 256>>>(table, (uint32_t)(table_bytes / 128 - 1), n_gathers / 2, sink); });
+  timed("calib_gather128_cached", (double)n_gathers * 64.0, [&] { calib_gather128<<<grid, 256>>>(table, (uint32_t)(((size_t)64 << 20) / 128 - 1), n_gathers / 2, sink); });
   timed("calib_gather64_x4", (double)n_gathers * 64.0, [&] { calib_gather64_x4<<<grid, 256>>>(table, node_mask, n_gathers, sink); });
   timed("calib_gather64_x4_cached", (double)n_gathers * 64.0, [&] { calib_gather64_x4<<<grid, 256>>>(table, (uint32_t)(((size_t)64 << 20) / 64 - 1), n_gathers, sink); });
   // the same gathers over 64 MiB, which the Infinity Cache holds: known_bytes is what is asked for, not what HBM gives
