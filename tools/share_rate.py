@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--sample-groups", type=int, nargs="*", default=None, help="sample ranges per strip set (c5: default 1 and 2)")
     ap.add_argument("--bands", type=int, nargs="*", default=[1], help="launches per share (render_and_combine overlaps the sums with > 1)")
     ap.add_argument("--pause", type=float, default=0.0, help="seconds of rest before each measurement (minutes of full load lower the clocks)")
+    ap.add_argument("--bounce-limit", type=int, default=50, help="path depth (50 is the configurations'; smaller values answer what long paths cost)")
     ap.add_argument("--whole-ms", type=float, default=0.0, help="the whole job's time if N = 1 is not in --ranks")
     args = ap.parse_args()
     w, h, spp = SHAPES[args.config]
@@ -62,7 +63,7 @@ def main():
             shares = rtd.split_interleaved(h, spp, n, sample_groups=groups)
             for rank in sorted({0, n - 1}):
                 for bands in args.bands:
-                    p = rtd.apply_share(rt.make_params(cam, w, h, spp), shares[rank])
+                    p = rtd.apply_share(rt.make_params(cam, w, h, spp, bounce_limit=args.bounce_limit), shares[rank])
                     t = time_share(r, p, bands, h, repeats, args.pause)
                     if whole is None:
                         whole = t * n
