@@ -48,7 +48,10 @@ __global__ __launch_bounds__(256) void rt_plan_count_kernel(const uint32_t* cost
 // run (whole lines, side by side), finding each job's pixel by bisection of the workgroup's 257 prefix sums.
 __global__ __launch_bounds__(256) void rt_plan_jobs_kernel(const uint32_t* order, const uint32_t* parts, const uint32_t* first,
                                                           uint32_t n, int sample_begin, int sample_end, int all_rows, int pairs,
-                                                          uint4* jobs, uint32_t* n_jobs) {
+                                                          uint4* jobs, uint32_t* n_jobs, const uint32_t* n_before) {
+  // (the jobs rt_probe_sum_kernel has made of given-up probe samples stand first in the table)
+  const uint32_t before = n_before ? *n_before : 0u;
+  jobs += before;
   __shared__ uint32_t start[257];
   const uint32_t i0 = blockIdx.x * 256, i = i0 + threadIdx.x;
   const uint32_t last = min(i0 + 256u, n) - 1u;  // the workgroup's last pixel
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256) void rt_plan_jobs_kernel(const uint32_t* order
     const int s1 = sample_begin + min(samples, unit * (int)(((long long)units * (part + 1)) / k));
     jobs[j] = make_uint4(order[pos], (uint32_t)s0, (uint32_t)s1, (k > 1 || all_rows) ? pos : RT_JOB_WHOLE);
   }
-  if (last == n - 1u && threadIdx.x == 0) *n_jobs = run_end;
+  if (last == n - 1u && threadIdx.x == 0) *n_jobs = before + run_end;
 }
 
 // Pixels that were cut into several jobs: the samples are added in sample order onto the sum the
@@ -78,7 +81,8 @@ __global__ __launch_bounds__(256) void rt_plan_jobs_kernel(const uint32_t* order
 __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order, const uint32_t* parts, uint32_t n_candidates,
                                                           const float* carry_colour, const float4* split_samples, int samples,
                                                           uint32_t n_rows, int tile_x0, int tile_y0, int tile_w, int width,
-                                                          int strip_count, int strip_index, int all_rows, int pairs, float* accum) {
+                                                          int strip_count, int strip_index, int all_rows, int pairs, float* accum,
+                                                          const uint32_t* redone, const float4* probe_samples, int n_probe, uint32_t probe_rows) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_candidates || (!all_rows && parts[i] <= 1u)) return;
   const uint32_t rect_pixel = order[i];
@@ -86,6 +90,14 @@ __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order
   float* dst = accum + 3 * ((size_t)y * (size_t)width + (size_t)x);
   const float* from = carry_colour ? carry_colour + 3 * (size_t)rect_pixel : dst;  // (no carried sums: the image's own)
   f3 colour = mk3(from[0], from[1], from[2]);
+  if (redone && redone[rect_pixel] != 0u) {
+    // some of the pixel's probe samples were rendered again by the main pass: the probe's sum anew, from the image
+    colour = mk3(dst[0], dst[1], dst[2]);
+    for (int s = 0; s < n_probe; s++) {
+      const float4 v = probe_samples[sample_slot((uint32_t)s, rect_pixel, probe_rows)];
+      colour = colour + mk3(v.x, v.y, v.z);
+    }
+  }
   if (pairs) {  // consecutive threads read consecutive 32-byte pairs of a plane
     for (int s = 0; s < samples; s += 2) {
       const float4* q = split_samples + pair_slot((uint32_t)s, i, n_rows);
@@ -111,26 +123,60 @@ __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order
 // sample ranges left in the image, exactly as one lane would have added them.  The sum goes to the
 // carry arrays (a probe: the main pass continues from it) or, with carry_colour null, back into the
 // image (a frame rendered in sweeps as a whole).
+// Samples whose path the probe gave up (RT_COST_ABORTED) become jobs of one sample each at the head of the main pass's
+// job table (redo_jobs, counted in n_redo: one atomic per workgroup), and their pixel is marked in carry_rng, for
+// rt_sum_split_kernel to form the probe's sum again once those samples are there.
 __global__ __launch_bounds__(256) void rt_probe_sum_kernel(uint32_t n_rect, const float4* probe_samples, int n_probe, int tile_x0,
                                                           int tile_y0, int tile_w, int width, int strip_count, int strip_index,
-                                                          float* accum, float* carry_colour, uint32_t* carry_rng, uint32_t* record_cost) {
+                                                          float* accum, float* carry_colour, uint32_t* carry_rng, uint32_t* record_cost,
+                                                          uint4* redo_jobs, uint32_t* n_redo, int sample_begin) {
+  __shared__ uint32_t wave_total[4];
+  __shared__ uint32_t block_base;
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_rect) return;
-  const int x = tile_x0 + (int)(i % (uint32_t)tile_w), y = real_row((int)(i / (uint32_t)tile_w), tile_y0, strip_count, strip_index);
-  float* base = accum + 3 * ((size_t)y * (size_t)width + (size_t)x);
-  f3 colour = mk3(base[0], base[1], base[2]);
-  uint32_t cost = 0u;
-  for (int s = 0; s < n_probe; s++) {  // consecutive threads read consecutive lines of a group's plane
-    const float4 v = probe_samples[sample_slot((uint32_t)s, i, n_rect)];
-    colour = colour + mk3(v.x, v.y, v.z);
-    cost += __float_as_uint(v.w);
+  const bool mine = i < n_rect;
+  f3 colour = mk3(0.0f, 0.0f, 0.0f);
+  uint32_t cost = 0u, given_up = 0u;  // bit s: sample s was given up
+  float* base = nullptr;
+  if (mine) {
+    const int x = tile_x0 + (int)(i % (uint32_t)tile_w), y = real_row((int)(i / (uint32_t)tile_w), tile_y0, strip_count, strip_index);
+    base = accum + 3 * ((size_t)y * (size_t)width + (size_t)x);
+    colour = mk3(base[0], base[1], base[2]);
+    for (int s = 0; s < n_probe; s++) {  // consecutive threads read consecutive lines of a group's plane
+      const float4 v = probe_samples[sample_slot((uint32_t)s, i, n_rect)];
+      colour = colour + mk3(v.x, v.y, v.z);
+      const uint32_t w = __float_as_uint(v.w);
+      cost += w & ~RT_COST_ABORTED;
+      if (redo_jobs != nullptr && (w & RT_COST_ABORTED) != 0u && s < 32) given_up |= 1u << s;
+    }
+    if (record_cost) record_cost[i] = cost;  // (records written by rt_render_stored_kernel carry the segments their path took)
+    float* dst = carry_colour ? carry_colour + 3 * (size_t)i : base;
+    dst[0] = colour.x;
+    dst[1] = colour.y;
+    dst[2] = colour.z;
+    if (carry_rng) carry_rng[i] = given_up != 0u ? 1u : 0u;  // (the counter RNG re-keys every sample: the word is free for the mark)
   }
-  if (record_cost) record_cost[i] = cost;  // (records written by rt_render_stored_kernel carry the segments their path took)
-  float* dst = carry_colour ? carry_colour + 3 * (size_t)i : base;
-  dst[0] = colour.x;
-  dst[1] = colour.y;
-  dst[2] = colour.z;
-  if (carry_rng) carry_rng[i] = 0u;  // the counter RNG re-keys every sample
+  if (redo_jobs == nullptr) return;
+  // places for the workgroup's jobs: prefix sums over the wave, the waves, and one atomic for the workgroup
+  const uint32_t mine_n = (uint32_t)__popc(given_up);
+  uint32_t incl = mine_n;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(incl, off, 64);
+    if ((int)(threadIdx.x & 63) >= off) incl += up;
+  }
+  if ((threadIdx.x & 63) == 63) wave_total[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t total = (wave_total[0] + wave_total[1]) + (wave_total[2] + wave_total[3]);
+    block_base = total != 0u ? atomicAdd(n_redo, total) : 0u;
+  }
+  __syncthreads();
+  uint32_t at = block_base + (incl - mine_n);
+  for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) at += wave_total[w];
+  while (given_up != 0u) {
+    const int s = __builtin_ctz(given_up);
+    given_up &= given_up - 1u;
+    redo_jobs[at++] = make_uint4(i, (uint32_t)(sample_begin + s), (uint32_t)(sample_begin + s + 1), RT_JOB_PROBE);
+  }
 }
 
 // Sort key of the main pass: the probe's cost in a few steps per power of two, most

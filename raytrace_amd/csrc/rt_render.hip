@@ -122,6 +122,15 @@ int sweeps_for(int n) {
   s = s > n ? n : s;
   return s < 1 ? 1 : s;
 }
+// Segments after which the probe pass gives a path up and leaves its sample to the main pass (render_args::probe_abort;
+// RT_PROBE_ABORT overrides, 0: never).  One rank's eighth of a 1920x1080 frame: probe pass 1.03 ms with paths run to
+// their end, 0.70 ms cut at 16 segments (3 % of the work lies beyond); the eighth as a whole 7.49 ms without,
+// 7.16 / 7.18 / 7.22 / 7.25 / 7.38 ms giving up after 8 / 12 / 16 / 24 / 32 segments, the whole frame 0.3 ms less too.
+int probe_abort_segments() {  // (read at every render, so that one process can compare)
+  const char* e = tuning_env("RT_PROBE_ABORT");
+  const int x = e ? atoi(e) : 12;
+  return x < 0 ? 0 : (x > 1000 ? 1000 : x);
+}
 bool stored_kernel_enabled() {  // RT_STORED_KERNEL=0: every pass in the kernel whose lanes own their pixels (comparison)
   static bool v = [] {
     const char* e = tuning_env("RT_STORED_KERNEL");
@@ -261,6 +270,10 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   a.split_rows = 0;
   a.carry_colour = nullptr;
   a.carry_rng = a.carry_cost = nullptr;
+  a.probe_abort = 0;
+  a.probe_store = nullptr;
+  a.probe_rows = 0;
+  a.probe_begin = 0;
   // A pixel is the unit of work (its sum must be formed in sample order), so
   // the launch ends with the lanes that drew the most expensive pixels last.
   // With enough samples a short probe pass measures every pixel's cost, the
@@ -293,7 +306,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
     if (e == hipSuccess) {
       rt_probe_sum_kernel<<<(unsigned)((n_rect + 255) / 256), 256, 0, c->stream>>>(
           (uint32_t)n_rect, reinterpret_cast<const float4*>(c->probe_samples.p), n_samples, p->tile_x0, p->tile_y0, tw, p->width,
-          p->strip_count, p->strip_index, c->accum(), nullptr, nullptr, nullptr);
+          p->strip_count, p->strip_index, c->accum(), nullptr, nullptr, nullptr, nullptr, nullptr, 0);
       e = hipGetLastError();
     }
   } else if (!two_pass) {
@@ -325,20 +338,40 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
     }
     const int sweeps = sweeps_for(n_probe);
     probe.p.sample_end = p->sample_begin + n_probe;
+    // Long probe paths are given up and rendered again by the main pass when that pass stores every sample of every
+    // pixel (decided here from the budget, before the probe runs; not in counted runs, whose counters are the frame's
+    // work and nothing twice).
+    HIP_TRY(c->plan_counts.resize(2));  // [0] jobs of the main pass, [1] of them probe samples to render again
+    HIP_TRY(hipMemsetAsync(c->plan_counts.p, 0, 2 * sizeof(uint32_t), c->stream));
+    bool redo = false;
+    {
+      const int ms = n_samples - n_probe;
+      const bool scans_ = c->search == SEARCH_LINEAR || c->search == SEARCH_LINEAR_LDS;
+      const size_t rows_fit = split_budget / (stored_samples(ms) * kSampleFloats * sizeof(float));
+      redo = swept && !counted && probe_abort_segments() > 0 && n_probe <= 32 && !scans_ && c->n_nodes >= 32 && split_rows() < 0 &&
+             rows_fit >= n_rect && (unsigned long long)n_rect * stored_samples(ms) < (1ull << 30) &&
+             (unsigned long long)n_rect * (unsigned long long)n_probe < (1ull << 30);
+      // (and only if the store is really to be had: without it the main pass could not take those samples)
+      if (redo && c->split_samples.fit(n_rect * stored_samples(ms) * kSampleFloats) != hipSuccess) redo = false;
+    }
     if (swept) {
       probe.pass = 3;
       probe.sweeps = sweeps;
       probe.split_samples = reinterpret_cast<float4*>(c->probe_samples.p);
       probe.main_samples = n_probe;
+      probe.probe_abort = redo ? probe_abort_segments() : 0;
     }
+    if (redo) HIP_TRY(c->plan_jobs.resize((size_t)n_rect * 8 + (size_t)c->n_cu * 1024 * (size_t)split_fineness() + 64 + n_rect * (size_t)n_probe));
     e = swept ? launch_stored_pass(probe) : launch(probe, p);
     if (e == hipSuccess && swept) {
       rt_probe_sum_kernel<<<(unsigned)((n_rect + 255) / 256), 256, 0, c->stream>>>(
           (uint32_t)n_rect, reinterpret_cast<const float4*>(c->probe_samples.p), n_probe, p->tile_x0, p->tile_y0, tw, p->width,
-          p->strip_count, p->strip_index, c->accum(), c->carry_colour.p, c->carry_rng.p, c->carry_cost.p);
+          p->strip_count, p->strip_index, c->accum(), c->carry_colour.p, c->carry_rng.p, c->carry_cost.p,
+          redo ? c->plan_jobs.p : nullptr, c->plan_counts.p + 1, p->sample_begin);
       e = hipGetLastError();
       probe.pass = 1;  // what follows copies `probe` for the main pass
       probe.sweeps = 1;
+      probe.probe_abort = 0;
     }
     if (e == hipSuccess) {
       rt_sort_key_kernel<<<(unsigned)((n_rect + 255) / 256), 256, 0, c->stream>>>((uint32_t)n_rect, tw, cost_steps_log2(), /*8x8 tiles*/ 3, c->carry_cost.p, c->carry_key.p,
@@ -396,9 +429,8 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       }
       HIP_TRY(c->plan_parts.resize(n));
       HIP_TRY(c->plan_first.resize(n));
-      HIP_TRY(c->plan_counts.resize(1));
       HIP_TRY(c->plan_total.resize(1));
-      HIP_TRY(c->plan_jobs.resize((size_t)n * (size_t)fewest + (size_t)lanes + 64));
+      if (!redo) HIP_TRY(c->plan_jobs.resize((size_t)n * (size_t)fewest + (size_t)lanes + 64));  // (with redo: sized before the probe, see there)
       size_t scan_bytes = 0;
       HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, c->plan_parts.p, c->plan_first.p, 0u, n, rocprim::plus<uint32_t>(), c->stream));
       HIP_TRY(c->scan_temp.resize(scan_bytes > 0 ? scan_bytes : 1));
@@ -421,6 +453,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
         const int all_rows = splittable && max_split >= n && stored_ok &&
                              (unsigned long long)n * stored_samples(main_samples) <= 0xFFFFFFFFull ? 1 : 0;
         if (chunk_len < n_samples && !all_rows) return fail(RT_ERR_DEVICE, "a chunk of %d samples has no row for every pixel", main_samples);
+        if (redo && first_chunk && !all_rows) return fail(RT_ERR_DEVICE, "probe samples were left to a main pass that cannot store them");
         // ... whose records go out in pairs, as long as the store stays below 2^31 records (a slot number's top bit
         // marks the record that waits); RT_SAMPLE_PAIRS=0: every record on its own (comparison)
         static const bool pairs_enabled = [] {
@@ -434,7 +467,8 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
         HIP_TRY(rocprim::exclusive_scan(c->scan_temp.p, scan_bytes, c->plan_parts.p, c->plan_first.p, 0u, n, rocprim::plus<uint32_t>(),
                                         c->stream));
         rt_plan_jobs_kernel<<<grid, 256, 0, c->stream>>>(c->order_idx.p, c->plan_parts.p, c->plan_first.p, n, main_begin,
-                                                        main_end, all_rows, pairs, c->plan_jobs.p, c->plan_counts.p);
+                                                        main_end, all_rows, pairs, c->plan_jobs.p, c->plan_counts.p,
+                                                        redo && first_chunk ? c->plan_counts.p + 1 : nullptr);
         HIP_TRY(hipGetLastError());
         render_args mainp = probe;
         mainp.pass = 2;
@@ -446,6 +480,11 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
         mainp.main_samples = main_samples;
         mainp.split_rows = n < max_split ? n : max_split;
         mainp.pairs = pairs;
+        if (redo && first_chunk) {
+          mainp.probe_store = reinterpret_cast<float4*>(c->probe_samples.p);
+          mainp.probe_rows = n;
+          mainp.probe_begin = p->sample_begin;
+        }
         // Not every pixel has a row: the same kernel in the form whose lanes sum whole pixels in registers (counter
         // generator; RT_OWNED_RESERVE=0 keeps the kernel without reserves, for comparison)
         static const bool owned_enabled = [] {
@@ -462,7 +501,9 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
           // (the first chunk continues the probe's sums, a later one what the chunk before it left in the image)
           rt_sum_split_kernel<<<(cand + 255) / 256, 256, 0, c->stream>>>(c->order_idx.p, c->plan_parts.p, cand, first_chunk ? c->carry_colour.p : nullptr,
                                                                         reinterpret_cast<const float4*>(c->split_samples.p), main_samples, cand, p->tile_x0, p->tile_y0,
-                                                                        tw, p->width, p->strip_count, p->strip_index, all_rows, pairs, c->accum());
+                                                                        tw, p->width, p->strip_count, p->strip_index, all_rows, pairs, c->accum(),
+                                                                        redo && first_chunk ? c->carry_rng.p : nullptr,
+                                                                        reinterpret_cast<const float4*>(c->probe_samples.p), n_probe, n);
           e = hipGetLastError();
         }
       }
