@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order
                                                           const float* carry_colour, const float4* split_samples, int samples,
                                                           uint32_t n_rows, int tile_x0, int tile_y0, int tile_w, int width,
                                                           int strip_count, int strip_index, int all_rows, int pairs, float* accum,
-                                                          const uint32_t* redone, const float4* probe_samples, int n_probe, uint32_t probe_rows) {
+                                                          const uint32_t* redone, const float4* probe_samples, int n_probe, uint32_t probe_rows,
+                                                          size_t redo_base) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_candidates || (!all_rows && parts[i] <= 1u)) return;
   const uint32_t rect_pixel = order[i];
@@ -94,7 +95,9 @@ __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order
     // some of the pixel's probe samples were rendered again by the main pass: the probe's sum anew, from the image
     colour = mk3(dst[0], dst[1], dst[2]);
     for (int s = 0; s < n_probe; s++) {
-      const float4 v = probe_samples[sample_slot((uint32_t)s, rect_pixel, probe_rows)];
+      float4 v = probe_samples[sample_slot((uint32_t)s, rect_pixel, probe_rows)];
+      // (a sample given up: its record names the job that rendered it again, and that job wrote behind the rows)
+      if ((__float_as_uint(v.w) & RT_COST_ABORTED) != 0u) v = split_samples[redo_base + 2 * (size_t)__float_as_uint(v.x)];
       colour = colour + mk3(v.x, v.y, v.z);
     }
   }
@@ -124,9 +127,10 @@ __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order
 // carry arrays (a probe: the main pass continues from it) or, with carry_colour null, back into the
 // image (a frame rendered in sweeps as a whole).
 // Samples whose path the probe gave up (RT_COST_ABORTED) become jobs of one sample each at the head of the main pass's
-// job table (redo_jobs, counted in n_redo: one atomic per workgroup), and their pixel is marked in carry_rng, for
-// rt_sum_split_kernel to form the probe's sum again once those samples are there.
-__global__ __launch_bounds__(256) void rt_probe_sum_kernel(uint32_t n_rect, const float4* probe_samples, int n_probe, int tile_x0,
+// job table (redo_jobs, counted in n_redo: one atomic per workgroup; the job's number goes into the sample's record),
+// and their pixel is marked in carry_rng, for rt_sum_split_kernel to form the probe's sum again once those samples
+// are there.
+__global__ __launch_bounds__(256) void rt_probe_sum_kernel(uint32_t n_rect, float4* probe_samples, int n_probe, int tile_x0,
                                                           int tile_y0, int tile_w, int width, int strip_count, int strip_index,
                                                           float* accum, float* carry_colour, uint32_t* carry_rng, uint32_t* record_cost,
                                                           uint4* redo_jobs, uint32_t* n_redo, int sample_begin) {
@@ -175,7 +179,9 @@ __global__ __launch_bounds__(256) void rt_probe_sum_kernel(uint32_t n_rect, cons
   while (given_up != 0u) {
     const int s = __builtin_ctz(given_up);
     given_up &= given_up - 1u;
-    redo_jobs[at++] = make_uint4(i, (uint32_t)(sample_begin + s), (uint32_t)(sample_begin + s + 1), RT_JOB_PROBE);
+    redo_jobs[at] = make_uint4(i, (uint32_t)(sample_begin + s), (uint32_t)(sample_begin + s + 1), RT_JOB_REDO | at);
+    probe_samples[sample_slot((uint32_t)s, i, n_rect)].x = __uint_as_float(at);  // where rt_sum_split_kernel finds the sample
+    at++;
   }
 }
 

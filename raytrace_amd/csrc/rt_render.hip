@@ -122,7 +122,7 @@ int sweeps_for(int n) {
   s = s > n ? n : s;
   return s < 1 ? 1 : s;
 }
-// Segments after which the probe pass gives a path up and leaves its sample to the main pass (render_args::probe_abort;
+// Segments after which the probe pass gives a path up and leaves its sample to the main pass (render_args, "long paths of the probe";
 // RT_PROBE_ABORT overrides, 0: never).  One rank's eighth of a 1920x1080 frame: probe pass 1.03 ms with paths run to
 // their end, 0.70 ms cut at 16 segments (3 % of the work lies beyond); the eighth as a whole 7.49 ms without,
 // 7.16 / 7.18 / 7.22 / 7.25 / 7.38 ms giving up after 8 / 12 / 16 / 24 / 32 segments, the whole frame 0.3 ms less too.
@@ -270,10 +270,6 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   a.split_rows = 0;
   a.carry_colour = nullptr;
   a.carry_rng = a.carry_cost = nullptr;
-  a.probe_abort = 0;
-  a.probe_store = nullptr;
-  a.probe_rows = 0;
-  a.probe_begin = 0;
   // A pixel is the unit of work (its sum must be formed in sample order), so
   // the launch ends with the lanes that drew the most expensive pixels last.
   // With enough samples a short probe pass measures every pixel's cost, the
@@ -305,7 +301,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
     e = launch_stored_pass(sw);
     if (e == hipSuccess) {
       rt_probe_sum_kernel<<<(unsigned)((n_rect + 255) / 256), 256, 0, c->stream>>>(
-          (uint32_t)n_rect, reinterpret_cast<const float4*>(c->probe_samples.p), n_samples, p->tile_x0, p->tile_y0, tw, p->width,
+          (uint32_t)n_rect, reinterpret_cast<float4*>(c->probe_samples.p), n_samples, p->tile_x0, p->tile_y0, tw, p->width,
           p->strip_count, p->strip_index, c->accum(), nullptr, nullptr, nullptr, nullptr, nullptr, 0);
       e = hipGetLastError();
     }
@@ -348,30 +344,31 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
       const int ms = n_samples - n_probe;
       const bool scans_ = c->search == SEARCH_LINEAR || c->search == SEARCH_LINEAR_LDS;
       const size_t rows_fit = split_budget / (stored_samples(ms) * kSampleFloats * sizeof(float));
+      // (the samples rendered again lie behind the rows of the main pass's store, two records apart: slot numbers stay
+      // below 2^31, whose bit marks a record that waits for its partner)
+      const unsigned long long records = (unsigned long long)n_rect * stored_samples(ms) + 2ull * n_rect * (unsigned long long)n_probe;
       redo = swept && !counted && probe_abort_segments() > 0 && n_probe <= 32 && !scans_ && c->n_nodes >= 32 && split_rows() < 0 &&
-             rows_fit >= n_rect && (unsigned long long)n_rect * stored_samples(ms) < (1ull << 30) &&
-             (unsigned long long)n_rect * (unsigned long long)n_probe < (1ull << 30);
+             rows_fit >= n_rect && records < (1ull << 31);
       // (and only if the store is really to be had: without it the main pass could not take those samples)
-      if (redo && c->split_samples.fit(n_rect * stored_samples(ms) * kSampleFloats) != hipSuccess) redo = false;
+      if (redo && c->split_samples.fit((size_t)records * kSampleFloats) != hipSuccess) redo = false;
     }
     if (swept) {
       probe.pass = 3;
       probe.sweeps = sweeps;
       probe.split_samples = reinterpret_cast<float4*>(c->probe_samples.p);
       probe.main_samples = n_probe;
-      probe.probe_abort = redo ? probe_abort_segments() : 0;
+      if (redo) probe.sweeps |= probe_abort_segments() << 16;  // (sweeps <= 64; see render_args)
     }
     if (redo) HIP_TRY(c->plan_jobs.resize((size_t)n_rect * 8 + (size_t)c->n_cu * 1024 * (size_t)split_fineness() + 64 + n_rect * (size_t)n_probe));
     e = swept ? launch_stored_pass(probe) : launch(probe, p);
     if (e == hipSuccess && swept) {
       rt_probe_sum_kernel<<<(unsigned)((n_rect + 255) / 256), 256, 0, c->stream>>>(
-          (uint32_t)n_rect, reinterpret_cast<const float4*>(c->probe_samples.p), n_probe, p->tile_x0, p->tile_y0, tw, p->width,
+          (uint32_t)n_rect, reinterpret_cast<float4*>(c->probe_samples.p), n_probe, p->tile_x0, p->tile_y0, tw, p->width,
           p->strip_count, p->strip_index, c->accum(), c->carry_colour.p, c->carry_rng.p, c->carry_cost.p,
           redo ? c->plan_jobs.p : nullptr, c->plan_counts.p + 1, p->sample_begin);
       e = hipGetLastError();
       probe.pass = 1;  // what follows copies `probe` for the main pass
       probe.sweeps = 1;
-      probe.probe_abort = 0;
     }
     if (e == hipSuccess) {
       rt_sort_key_kernel<<<(unsigned)((n_rect + 255) / 256), 256, 0, c->stream>>>((uint32_t)n_rect, tw, cost_steps_log2(), /*8x8 tiles*/ 3, c->carry_cost.p, c->carry_key.p,
@@ -480,11 +477,6 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
         mainp.main_samples = main_samples;
         mainp.split_rows = n < max_split ? n : max_split;
         mainp.pairs = pairs;
-        if (redo && first_chunk) {
-          mainp.probe_store = reinterpret_cast<float4*>(c->probe_samples.p);
-          mainp.probe_rows = n;
-          mainp.probe_begin = p->sample_begin;
-        }
         // Not every pixel has a row: the same kernel in the form whose lanes sum whole pixels in registers (counter
         // generator; RT_OWNED_RESERVE=0 keeps the kernel without reserves, for comparison)
         static const bool owned_enabled = [] {
@@ -503,7 +495,8 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
                                                                         reinterpret_cast<const float4*>(c->split_samples.p), main_samples, cand, p->tile_x0, p->tile_y0,
                                                                         tw, p->width, p->strip_count, p->strip_index, all_rows, pairs, c->accum(),
                                                                         redo && first_chunk ? c->carry_rng.p : nullptr,
-                                                                        reinterpret_cast<const float4*>(c->probe_samples.p), n_probe, n);
+                                                                        reinterpret_cast<const float4*>(c->probe_samples.p), n_probe, n,
+                                                                        (size_t)cand * stored_samples(main_samples));
           e = hipGetLastError();
         }
       }

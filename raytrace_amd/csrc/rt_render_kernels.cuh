@@ -44,20 +44,16 @@ struct render_args {
   int main_samples;            // samples per pixel of the main pass
   uint32_t split_rows;         // rows of split_samples
   // Long paths of the probe.  A probe in sweeps ends with the lanes that drew a path of dozens of segments working
-  // alone.  With probe_abort > 0, pass 3 gives a path up when it is about to begin segment probe_abort + 1: the
-  // sample's record says so (RT_COST_ABORTED in its cost word), rt_probe_sum_kernel turns it into a job of its own at
-  // the head of the main pass's job table (RT_JOB_PROBE), and pass 2 renders that sample again — same counter key, so
-  // the same path, to its end — into the record's place in the probe's store (probe_store, probe_rows, probe_begin).
-  int probe_abort;
-  float4* probe_store;
-  uint32_t probe_rows;
-  int probe_begin;
+  // alone.  With a threshold in the upper half of `sweeps` (pass 3), a path about to begin one more segment than that
+  // is given up: the sample's record says so (RT_COST_ABORTED in its cost word), rt_probe_sum_kernel turns it into
+  // job k of the jobs at the head of the main pass's table (fourth word RT_JOB_REDO | k), and pass 2 renders that
+  // sample again — same counter key, so the same path, to its end — into record 2 k behind the rows of its own store.
+  // (Nothing else of the kernel knows: such a record is written like any other.)
 };
 
 #define RT_JOB_WHOLE 0xFFFFFFFFu
-#define RT_JOB_PROBE 0xFFFFFFFEu     // a job's fourth word: one sample of the probe pass, to be rendered again
+#define RT_JOB_REDO 0x80000000u      // in a job's fourth word (kernels whose every pixel has a row): probe sample to render again, see above
 #define RT_COST_ABORTED 0x80000000u  // in a probe record's cost word: the path was given up after that many segments
-#define RT_SLOT_PROBE 0x40000000u    // in a slot number (pass 2): the record's place is in the probe's store
 
 // Where the record of sample s (counted from the first sample of the pass) of row r lies in a per-sample store of
 // `rows` rows: sample-major, plane s holds that sample of every row, so that lanes holding neighbouring rows write next
@@ -407,7 +403,8 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
   const int tw = P.tile_x1 - P.tile_x0, th = A.vrows;
   const int tiles_x = (tw + 7) >> 3, tiles_y = (th + 7) >> 3;
   const uint32_t tile_items = (uint32_t)tiles_x * (uint32_t)tiles_y * 64u;
-  const uint32_t total_items = A.pass == 2 ? *A.n_jobs : tile_items * (uint32_t)A.sweeps;
+  const uint32_t n_sweeps = (uint32_t)A.sweeps & 0xFFFFu, abort_after = A.pass == 3 ? (uint32_t)A.sweeps >> 16 : 0u;
+  const uint32_t total_items = A.pass == 2 ? *A.n_jobs : tile_items * n_sweeps;
   const size_t rows = A.pass == 3 ? (size_t)tw * (size_t)th : (size_t)A.split_rows;
 
   lane_counters k = {};
@@ -467,10 +464,6 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
             dst[1] = colour.y;
             dst[2] = colour.z;
           }
-        } else if (!OWNED && A.probe_store != nullptr && (cur_slot & RT_SLOT_PROBE) != 0u) {
-          // a probe sample rendered again.  (Only in launches that were given the probe's store: there the host keeps
-          // both stores below 2^30 records, so that the bit is free; a larger store's own slot numbers reach it.)
-          A.probe_store[cur_slot & ~RT_SLOT_PROBE] = make_float4(alb.x, alb.y, alb.z, __uint_as_float(path_segments));
         } else if (pairs && (cur_slot & RT_SLOT_HOLD) != 0u) {
           held = alb;
         } else {
@@ -480,8 +473,8 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
         }
         st &= ~ALIVE;
       }
-      if (!OWNED && start_segment && A.probe_abort > 0 && path_segments >= (uint32_t)A.probe_abort) {
-        // pass 3 only: the path is left to a job of the main pass (render_args::probe_abort)
+      if (!OWNED && start_segment && abort_after != 0u && path_segments >= abort_after) {
+        // pass 3 only: the path is left to a job of the main pass (render_args, "long paths of the probe")
         A.split_samples[cur_slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(RT_COST_ABORTED | path_segments));
         start_segment = false;
         st &= ~ALIVE;
@@ -534,8 +527,8 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
               const uint32_t sweep = item / tile_items, it = item - sweep * tile_items;
               // (32-bit arithmetic: the host runs a pass in sweeps only over fewer than 2^24 samples, in at most 64 sweeps)
               const uint32_t n_all = (uint32_t)(P.sample_end - P.sample_begin);
-              js = P.sample_begin + (int)(n_all * sweep / (uint32_t)A.sweeps);
-              js_end = P.sample_begin + (int)((n_all * sweep + n_all) / (uint32_t)A.sweeps);
+              js = P.sample_begin + (int)(n_all * sweep / n_sweeps);
+              js_end = P.sample_begin + (int)((n_all * sweep + n_all) / n_sweeps);
               const uint32_t tile = it >> 6, within = it & 63u;
               jx = P.tile_x0 + (int)(tile % (uint32_t)tiles_x) * 8 + (int)(within & 7u);
               vy = (int)(tile / (uint32_t)tiles_x) * 8 + (int)(within >> 3);
@@ -555,7 +548,7 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
           const uint32_t s_rel = (uint32_t)(js - P.sample_begin);
           uint32_t slot = (uint32_t)sample_slot(s_rel, (size_t)jrow, rows);
           if (pairs) slot = (uint32_t)pair_slot(s_rel, (size_t)jrow, rows) | ((s_rel & 1u) == 0u && js + 1 < js_end ? RT_SLOT_HOLD : 0u);
-          if (!OWNED && A.probe_store != nullptr && jrow == RT_JOB_PROBE) slot = RT_SLOT_PROBE | (uint32_t)sample_slot((uint32_t)(js - A.probe_begin), (size_t)jrect, (size_t)A.probe_rows);
+          if (!OWNED && (jrow & RT_JOB_REDO) != 0u) slot = (uint32_t)rows * (((uint32_t)A.main_samples + 1u) & ~1u) + 2u * (jrow & ~RT_JOB_REDO);  // (an even slot: written alone)
           if (OWNED && jrow == RT_JOB_WHOLE)
             slot = RT_TAG_WHOLE | (has(JOB_FIRST) ? RT_TAG_FIRST : 0u) | (js + 1 < js_end ? 0u : RT_TAG_LAST) | jrect;
           st &= ~JOB_FIRST;
