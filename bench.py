@@ -108,7 +108,7 @@ def parse_args():
     ap.add_argument("--collective", choices=["gather", "reduce"], default="gather",
                     help="strip shares (N > 1): gather each rank's rows onto rank 0, or sum whole accumulators")
     ap.add_argument("--sample-groups", type=int, default=0,
-                    help="c5 with N > 1: sample ranges per strip set (0: chosen from a share's pixels per lane, see c5_sample_groups)")
+                    help="c5 with N > 1: sample ranges per strip set (0: one — strips only, rows gathered)")
     ap.add_argument("--no-extras", action="store_true", help="skip the linear-scan, c3, c4 and weak-scaling legs")
     return ap.parse_args()
 
@@ -230,17 +230,12 @@ def trace_workload(rt, torch, r, dev, args, cfg, rank, world, accel):
 
 
 def c5_sample_groups(args, world, pixels, lanes):
-    """Sample ranges per strip set of a strong-scaling frame with very many samples.  A share's pixels per lane decide:
-    up to 6 the library renders the share in chunks of samples with every sample stored, from about 12 on its lanes
-    sum whole pixels in registers, and both schedules keep the lanes busy (tools/share_rate.py --config c5: within
-    3 % of the whole job / N).  A share in between balances badly, so ranks pair up on larger strip sets and halve the
-    samples instead: c5 on four ranks (8 pixels per lane each) runs as 2 strip sets x 2 sample ranges."""
-    if args.sample_groups > 0:
-        return args.sample_groups
-    g = 1
-    while world % (2 * g) == 0 and 6 * lanes < pixels * g // world < 12 * lanes:
-        g *= 2
-    return g
+    """Sample ranges per strip set of a strong-scaling frame with very many samples: one, unless --sample-groups asks
+    for more.  Strips alone need no sum (every rank's rows are gathered), and the library schedules a share of any
+    size well: up to six pixels per lane in chunks of samples with every sample stored, six to twenty-four as several
+    such parts, beyond that with whole pixels as jobs (tools/share_rate.py --config c5: 0.99 to 1.02 of the whole job / N for
+    N = 2, 4, 8)."""
+    return args.sample_groups if args.sample_groups > 0 else 1
 
 
 def render_workload(rt, torch, dist, r, dev, args, cfg, rank, world, accel, sid, overrides=True):

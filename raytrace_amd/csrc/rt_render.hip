@@ -191,7 +191,7 @@ int refill_min() {
   return v;
 }
 
-int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
+int render_impl(rt_ctx* c, const rt_params* p, bool counted, bool nested = false) {
   int rc = check_ctx(c);
   if (rc) return rc;
   rc = check_params(c, p);
@@ -235,7 +235,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   }
   if (counted) {
     HIP_TRY(c->counters.resize(sizeof(rt_counters) / sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(rt_counters), c->stream));
+    if (!nested) HIP_TRY(hipMemsetAsync(c->counters.p, 0, sizeof(rt_counters), c->stream));
     a.counters = c->counters.p;
   }
   const int tw = p->tile_x1 - p->tile_x0, th = share_rows(p);
@@ -281,12 +281,40 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   // cannot start in the middle of a pixel, so there a probe pays from 16 samples on: 1080p x 32 spp 3 360 -> 4 340 Mpaths/s)
   const int min_two_pass = p->rng_mode == RT_RNG_COUNTER ? kMinTwoPassSamples : kMinTwoPassSamplesSequential;
   const bool two_pass = two_pass_enabled() && n_samples >= min_two_pass && n_rect >= 16384;
-  HIP_TRY(hipEventRecord(c->ev_k0, c->stream));
+  if (!nested) HIP_TRY(hipEventRecord(c->ev_k0, c->stream));
   hipError_t e;
   // Few samples, counter RNG: the frame as a whole is rendered in sweeps (short jobs in tile order, per-sample
   // radiance summed in order afterwards) — a pixel per job would end with the expensive pixels' lanes working alone.
   size_t split_budget, probe_budget;
   scratch_budgets(c, split_budget, probe_budget);
+  // A long sample range on a middling number of pixels (six to twenty-four per lane), where the store cannot give
+  // every pixel a row: whole pixels as jobs balance badly there (a quarter of a 3840x2160x4096 frame, eight pixels
+  // per lane: 867 ms against 780 for a quarter of the whole frame's time; half of it, sixteen per lane: 1 600 to
+  // 1 680 ms against 1 565), and chunks of samples (below) want fewer pixels.  Such a share is rendered as smaller ones
+  // one after the other — interleaved strip sets of its own strips, four pixels per lane each — which the chunks
+  // then take: 799 to 804 ms, and 1 592 to 1 598.  The pixels of the parts are disjoint, so the image is the same.
+  // With still more pixels per lane whole-pixel jobs do well (the whole frame, 32 per lane: 3.13 s, in eight parts
+  // 3.19 s: every part has a probe pass and tails of its own).  (RT_SAMPLE_CHUNKS=0: never.)
+  if (!nested && two_pass && stored_ok && p->rng_mode == RT_RNG_COUNTER && split_rows() < 0 && c->n_nodes >= 32 &&
+      !(c->search == SEARCH_LINEAR || c->search == SEARCH_LINEAR_LDS) && !(tuning_env("RT_SAMPLE_CHUNKS") && tuning_env("RT_SAMPLE_CHUNKS")[0] == '0')) {
+    const size_t lanes = (size_t)c->n_cu * 1024, most = 4 * lanes;
+    const size_t fit_samples = split_budget / (n_rect * kSampleFloats * sizeof(float));
+    if (n_rect > 6 * lanes && n_rect < 24 * lanes && fit_samples < stored_samples(n_samples - probe_samples(n_samples, true))) {
+      const int parts = (int)((n_rect + most - 1) / most), mine = p->strip_count ? p->strip_count : 1;
+      if ((long long)mine * parts <= 65535) {
+        for (int j = 0; j < parts; j++) {
+          rt_params q = *p;
+          q.strip_count = (uint16_t)(mine * parts);
+          q.strip_index = (uint16_t)(p->strip_index + mine * j);
+          const int rc = render_impl(c, &q, counted, true);
+          if (rc) return rc;
+        }
+        HIP_TRY(hipEventRecord(c->ev_k1, c->stream));
+        c->have_kernel_time = true;
+        return RT_OK;
+      }
+    }
+  }
   bool whole_in_sweeps = !two_pass && two_pass_enabled() && stored_ok && probe_sweeps() > 1 &&
                          n_samples >= 2 && n_rect >= 16384 &&
                          n_rect * stored_samples(n_samples) * kSampleFloats * sizeof(float) <= probe_budget;
@@ -504,6 +532,7 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted) {
   }
   if (e != hipSuccess) return fail(RT_ERR_DEVICE, "render launch: %s", hipGetErrorString(e));
   c->last_kernel = used_stored ? stored_name(c->search) : search_name(c->search, true);
+  if (nested) return RT_OK;
   HIP_TRY(hipEventRecord(c->ev_k1, c->stream));
   c->have_kernel_time = true;
   return RT_OK;

@@ -49,17 +49,13 @@ def test_read_factors():
     assert tool.read_factor("rt_render_stored_kernel<1, false, false, false>") == 2.0
 
 
-def test_c5_sample_ranges_follow_a_shares_pixels_per_lane():
-    """bench.py --config c5 on N ranks: strips alone where a share has up to six or at least twelve pixels per lane,
-    pairs of ranks on larger strip sets with half the samples each in between."""
+def test_c5_shares_are_strips_unless_asked_otherwise():
+    """bench.py --config c5 on N ranks: interleaved strip sets of all samples each (rows gathered, nothing summed);
+    --sample-groups G pairs ranks up on larger strip sets with a G-th of the samples each."""
     import types
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    args = types.SimpleNamespace(sample_groups=0)
     pixels, lanes = 3840 * 2160, 256 * 1024
-    assert [bench.c5_sample_groups(args, n, pixels, lanes) for n in (1, 2, 3, 4, 8, 16)] == [1, 1, 1, 2, 1, 1]
+    assert [bench.c5_sample_groups(types.SimpleNamespace(sample_groups=0), n, pixels, lanes) for n in (1, 2, 4, 8)] == [1, 1, 1, 1]
     assert bench.c5_sample_groups(types.SimpleNamespace(sample_groups=4), 8, pixels, lanes) == 4
-    # a frame four times smaller: two ranks already fall into the gap
-    assert bench.c5_sample_groups(args, 2, 1920 * 1080, lanes) == 1   # 4 pixels per lane: chunks of samples
-    assert bench.c5_sample_groups(args, 1, 1920 * 1080, lanes) == 1   # (7.9 pixels per lane, but one rank cannot pair up)
