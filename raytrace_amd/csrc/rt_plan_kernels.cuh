@@ -97,19 +97,24 @@ __global__ __launch_bounds__(256) void rt_sum_split_kernel(const uint32_t* order
     for (int s = 0; s < n_probe; s++) {
       float4 v = probe_samples[sample_slot((uint32_t)s, rect_pixel, probe_rows)];
       // (a sample given up: its record names the job that rendered it again, and that job wrote behind the rows)
-      if ((__float_as_uint(v.w) & RT_COST_ABORTED) != 0u) v = split_samples[redo_base + 2 * (size_t)__float_as_uint(v.x)];
+      if ((__float_as_uint(v.w) & RT_COST_ABORTED) != 0u) {
+        const size_t slot = redo_base + 2 * (size_t)__float_as_uint(v.x);
+        if (pairs) {  // (24-byte pairs: the sample is the first of pair slot / 2)
+          const float* q = reinterpret_cast<const float*>(split_samples) + 6 * (slot >> 1);
+          v = make_float4(q[0], q[1], q[2], 0.0f);
+        } else {
+          v = split_samples[slot];
+        }
+      }
       colour = colour + mk3(v.x, v.y, v.z);
     }
   }
-  if (pairs) {  // consecutive threads read consecutive 32-byte pairs of a plane
+  if (pairs) {  // consecutive threads read consecutive 24-byte pairs of a plane (rt_render_stored_kernel writes them)
     for (int s = 0; s < samples; s += 2) {
-      const float4* q = split_samples + pair_slot((uint32_t)s, i, n_rows);
-      const float4 v0 = q[0];
-      colour = colour + mk3(v0.x, v0.y, v0.z);
-      if (s + 1 < samples) {
-        const float4 v1 = q[1];
-        colour = colour + mk3(v1.x, v1.y, v1.z);
-      }
+      const float2* q = reinterpret_cast<const float2*>(split_samples) + 3 * (pair_slot((uint32_t)s, i, n_rows) >> 1);
+      const float2 a = q[0], b = q[1], c = q[2];
+      colour = colour + mk3(a.x, a.y, b.x);
+      if (s + 1 < samples) colour = colour + mk3(b.y, c.x, c.y);
     }
   } else {
     for (int s = 0; s < samples; s++) {  // consecutive threads read consecutive lines of a group's plane

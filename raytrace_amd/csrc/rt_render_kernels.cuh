@@ -61,8 +61,9 @@ struct render_args {
 // samples of a row in one 64-byte line, written by one lane over time — the L2 does not hold the line until it is
 // complete, 22 GB written per C2 frame against 17 GB.)
 RT_DEV size_t sample_slot(uint32_t s, size_t r, size_t rows) { return (size_t)s * rows + r; }
-// Records in pairs (main pass of rt_render_stored_kernel): samples 2q and 2q + 1 of a row lie next to each other, 32
-// bytes that one lane writes at once; plane q holds pair q of every row.  RT_SLOT_HOLD in a slot number: the record
+// Records in pairs (main pass of rt_render_stored_kernel): samples 2q and 2q + 1 of a row lie next to each other and
+// one lane writes them at once; plane q holds pair q of every row.  A slot number counts records as if they were 16
+// bytes each; the pair slot / 2 itself is 24 bytes, two radiances, at 24 * (slot / 2).  RT_SLOT_HOLD in a slot number: the record
 // waits in the lane's registers for its partner (the store holds fewer than 2^31 records).
 #define RT_SLOT_HOLD 0x80000000u
 RT_DEV size_t pair_slot(uint32_t s, size_t r, size_t rows) { return ((size_t)(s >> 1) * rows + r) * 2 + (s & 1u); }
@@ -466,9 +467,20 @@ __global__ __launch_bounds__(search_traits<SEARCH>::threads, search_traits<SEARC
           }
         } else if (pairs && (cur_slot & RT_SLOT_HOLD) != 0u) {
           held = alb;
+        } else if (pairs) {
+          // Pair q of the store is 24 bytes — the radiance of its two samples, nothing else — at q * 24.  An odd
+          // record always follows its partner in this lane (jobs begin at even samples): both go out together; an
+          // even record that comes here is the only one of its pair (a job's last sample, a probe sample rendered again).
+          float2* q = reinterpret_cast<float2*>(A.split_samples) + 3 * (size_t)(cur_slot >> 1);
+          if ((cur_slot & 1u) != 0u) {
+            q[0] = make_float2(held.x, held.y);
+            q[1] = make_float2(held.z, alb.x);
+            q[2] = make_float2(alb.y, alb.z);
+          } else {
+            q[0] = make_float2(alb.x, alb.y);
+            reinterpret_cast<float*>(q)[2] = alb.z;
+          }
         } else {
-          // (an odd record of a pair always follows its partner in this lane: jobs begin at even samples)
-          if (pairs && (cur_slot & 1u) != 0u) A.split_samples[cur_slot - 1u] = make_float4(held.x, held.y, held.z, 0.0f);
           A.split_samples[cur_slot] = make_float4(alb.x, alb.y, alb.z, __uint_as_float(path_segments));
         }
         st &= ~ALIVE;
