@@ -380,7 +380,9 @@ int render_impl(rt_ctx* c, const rt_params* p, bool counted, bool nested = false
       // (the samples rendered again lie behind the rows of the main pass's store, two records apart: slot numbers stay
       // below 2^31, whose bit marks a record that waits for its partner)
       const unsigned long long records = (unsigned long long)n_rect * stored_samples(ms) + 2ull * n_rect * (unsigned long long)n_probe;
-      redo = swept && !counted && probe_abort_segments() > 0 && n_probe <= 32 && !scans_ && c->n_nodes >= 32 && split_rows() < 0 &&
+      // (where the main pass will give every pixel a row: a real tree, or a scan over many spheres — `heavy` below)
+      const bool heavy_ = (!scans_ && c->n_nodes >= 32) || (scans_ && c->n_spheres >= 64);
+      redo = swept && !counted && probe_abort_segments() > 0 && n_probe <= 32 && heavy_ && split_rows() < 0 &&
              rows_fit >= n_rect && records < (1ull << 31);
       // (and only if the store is really to be had: without it the main pass could not take those samples)
       if (redo && c->split_samples.fit((size_t)records * kSampleFloats) != hipSuccess) redo = false;

@@ -279,32 +279,31 @@ def test_sample_chunks_give_the_frame_of_one_pass(renderer, strips):
 @pytest.mark.parametrize("give_up_after", [1, 3, 12, 0])
 def test_probe_paths_given_up_and_rendered_again(renderer, monkeypatch, give_up_after):
     """The probe pass of a two-pass frame gives a path up after so many segments and leaves the sample to a job of the
-    main pass, which renders it again from its counter key into the probe's store; the sums are formed once it is
-    there.  Bit for bit the oracle's frame whether nearly every sample goes that way (1), many (3), few (12, the default), none (0);
-    whole and as one rank's strips."""
+    main pass, which renders it again from its counter key; the sums are formed once it is there.  Bit for bit the
+    oracle's frame whether nearly every sample goes that way (1), many (3), few (12, the default), none (0); whole and
+    as one rank's strips; with the tree and with the scan over the 487 spheres."""
     monkeypatch.setenv("RT_PROBE_ABORT", str(give_up_after))
     scene = rt.build_scene(rt.SCENE_RANDOM_SPHERES)
     cam = rt.scene_camera(rt.SCENE_RANDOM_SPHERES)
     w, h, spp = 256, 144, 64
-    renderer.upload(scene, rt.ACCEL_LBVH)
     for strips in (0, 2):
         p = rt.make_params(cam, w, h, spp, rng_mode=rt.RNG_COUNTER)
-        if strips:
-            p.strip_count, p.strip_index = strips, 1
-        acc, _ = oracle.render(scene, p, threads=8)
-        want = oracle.resolve(acc, spp)[0]
-        renderer.clear()
-        renderer.render(p)
-        assert_same_f32(renderer.readback(rgb8=False)[0], want, f"given up after {give_up_after}, strips {strips}")
-        assert renderer.last_kernel_ms()[1] == "rt_render_stored_kernel<lbvh4,lds,pad_ray>"
-        # a second render onto the first: the sums go on from the image
-        renderer.render(rt.make_params(cam, w, h, spp, rng_mode=rt.RNG_COUNTER, sample_begin=spp) if not strips else _next_range(p, spp))
         both = rt.make_params(cam, w, h, 2 * spp, rng_mode=rt.RNG_COUNTER)
         if strips:
+            p.strip_count, p.strip_index = strips, 1
             both.strip_count, both.strip_index = strips, 1
-        acc2, _ = oracle.render(scene, both, threads=8)
-        renderer.set_accumulated_samples(2 * spp)
-        assert_same_f32(renderer.readback(rgb8=False)[0], oracle.resolve(acc2, 2 * spp)[0], "two ranges in a row")
+        want = oracle.resolve(oracle.render(scene, p, threads=8)[0], spp)[0]
+        want2 = oracle.resolve(oracle.render(scene, both, threads=8)[0], 2 * spp)[0]
+        for accel, kernel in ((rt.ACCEL_LBVH, "rt_render_stored_kernel<lbvh4,lds,pad_ray>"), (rt.ACCEL_LINEAR, "rt_render_stored_kernel<linear,lds>")):
+            renderer.upload(scene, accel)
+            renderer.clear()
+            renderer.render(p)
+            assert_same_f32(renderer.readback(rgb8=False)[0], want, f"given up after {give_up_after}, strips {strips}, accel {accel}")
+            assert renderer.last_kernel_ms()[1] == kernel
+            # a second render onto the first: the sums go on from the image
+            renderer.render(_next_range(p, spp))
+            renderer.set_accumulated_samples(2 * spp)
+            assert_same_f32(renderer.readback(rgb8=False)[0], want2, "two ranges in a row")
 
 
 def _next_range(p, spp):
